@@ -1,0 +1,261 @@
+/*
+ * pcmi.h -- C ABI of libpcmi.so: the MI355X-native (gfx950 / CDNA4) sparse-voxel
+ * contrastive pre-training hot path.
+ *
+ * This library replaces, for the path named by BASELINE.json:north_star, what the
+ * reference reaches through MinkowskiEngine 0.4.3's pybind11 backend
+ * ("MinkowskiEngineBackend", third-party, not vendored under /root/reference) and
+ * a handful of torch ops.  Each entry point cites the reference call site it
+ * replaces ("pc/" = /root/reference/pretrain/pointcontrast/).
+ *
+ * Conventions
+ *   - every function returns PCMI_OK (0) or a negative PCMI_ERR_* code; the message
+ *     of the last failure on the calling thread is pcmi_last_error();
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor's
+ *     data_ptr) unless its name ends in _host;
+ *   - every call takes the HIP stream to enqueue on (pcmi_stream_t == hipStream_t);
+ *     nothing synchronises except where the comment says "syncs";
+ *   - float tensors are row-major fp32 [rows, channels] with an explicit leading
+ *     dimension (*_ld, in floats) so producers can write into column slices of a
+ *     wider buffer (zero-copy concat, pc/model/res16unet.py:235,242,249,256);
+ *   - ops never allocate device memory: scratch comes from the caller through
+ *     (ws, ws_bytes), sized by the matching *_workspace_bytes() query.  The one
+ *     exception is the coordinate manager, which owns an arena that is reused
+ *     across pcmi_coords_reset() calls (one hipMalloc burst in the first
+ *     iterations, none in steady state);
+ *   - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef PCMI_H_
+#define PCMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCMI_OK 0
+#define PCMI_ERR_INVALID (-1)     /* bad argument / shape */
+#define PCMI_ERR_HIP (-2)         /* HIP runtime failure */
+#define PCMI_ERR_DUPLICATE (-3)   /* duplicate coordinates in pcmi_coords_insert */
+#define PCMI_ERR_NOKEY (-4)       /* unknown coords key */
+#define PCMI_ERR_RANGE (-5)       /* coordinate outside the packable range */
+#define PCMI_ERR_UNSUPPORTED (-6) /* configuration outside the hot path */
+#define PCMI_ERR_WORKSPACE (-7)   /* workspace too small */
+
+/* ME.RegionType values used by the path (pc/model/modules/common.py:47-60). */
+#define PCMI_REGION_HYPERCUBE 0
+#define PCMI_REGION_HYBRID 3
+
+#define PCMI_MAX_KERNEL_VOLUME 27
+
+typedef void* pcmi_stream_t; /* hipStream_t */
+typedef struct pcmi_coords pcmi_coords_t;
+
+int pcmi_version(void);
+const char* pcmi_last_error(void);
+/* Number of compute units / arch name of the current HIP device (gfx950 expected). */
+int pcmi_device_info(int* n_cu, char* arch_host, int arch_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Coordinate manager -- replaces ME CoordsManager / CoordsKey
+ *   ME.SparseTensor(feats, coords=...)             pc/lib/ddp_trainer.py:290-297,392-398
+ *   strided coordinates of every stride-2 conv     pc/model/res16unet.py:58-64,75-81,92-98,109-115
+ * Coordinates are int32 rows (batch, x, y, z), batch index FIRST
+ * (pc/lib/ddp_data_loaders.py:68-76); |x|,|y|,|z| < 2^17, 0 <= batch < 1023.
+ * Key 0 is the inserted set (tensor stride 1); row i of a feature matrix belongs to
+ * row i of its key's coordinates.
+ * ------------------------------------------------------------------------------------------ */
+int pcmi_coords_create(int dimension /* must be 3 */, pcmi_coords_t** out);
+int pcmi_coords_destroy(pcmi_coords_t* h);
+/* Forget all keys and maps but keep the device arena (one manager per SparseTensor per
+ * iteration in the reference; here a pooled handle is reset instead). */
+int pcmi_coords_reset(pcmi_coords_t* h);
+/* Build the hash of n rows -> key 0.  Syncs (returns PCMI_ERR_DUPLICATE / PCMI_ERR_RANGE). */
+int pcmi_coords_insert(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream);
+/* Strided coordinates: unique floor(c / (stride*ts)) * (stride*ts); rows are in
+ * first-occurrence order of the input rows.  Cached per tensor stride.  Syncs on a miss. */
+int pcmi_coords_stride(pcmi_coords_t* h, int in_key, int stride, int* out_key, int64_t* n_out,
+                       pcmi_stream_t stream);
+int pcmi_coords_key_at_stride(pcmi_coords_t* h, int tensor_stride, int* key);
+int pcmi_coords_size(pcmi_coords_t* h, int key, int64_t* n, int* tensor_stride);
+/* Copy the key's coordinates into out_bxyz [n,4] (device). */
+int pcmi_coords_get(pcmi_coords_t* h, int key, int32_t* out_bxyz, pcmi_stream_t stream);
+/* Build every level (strides 2,4,..,2^n_down) and the kernel maps a Res16UNet forward
+ * uses up front (typically on a side stream while the compute stream is still busy), so
+ * the per-layer calls below all hit the cache and never sync.  Pure performance hint.  first_region: region of the 3^3 stem conv (HYPERCUBE),
+ * block_region: region of the 3^3 block convs (HYBRID). */
+int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int block_region,
+                          pcmi_stream_t stream);
+/* Bytes currently reserved by the handle's arena (for memory accounting). */
+int pcmi_coords_arena_bytes(pcmi_coords_t* h, size_t* bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel maps -- replaces CoordsManager::getInOutMaps (reached from every
+ * MinkowskiConvolution / MinkowskiConvolutionTranspose forward,
+ * pc/model/modules/common.py:130-139,159-168).
+ * Pair (i, j, k): in-row i feeds out-row j through weight slice k iff
+ *   c_out[j] + offset_k * tensor_stride(in) == c_in[i].
+ * Offsets in weight-slice order come from pcmi_kernel_offsets().
+ * All pointers live in the handle's arena and stay valid until reset/destroy.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pcmi_kmap {
+  int32_t K;               /* kernel volume (27, 8) */
+  int32_t kernel_size;     /* 3 or 2 */
+  int32_t stride;          /* 1 or 2 */
+  int32_t region;
+  int64_t n_in, n_out;
+  int64_t M;               /* total number of pairs */
+  const int32_t* nbr;      /* [K, n_out]: in-row for (k, out-row) or -1 */
+  const int32_t* pair_in;  /* [M] grouped by k, ascending out-row inside a group */
+  const int32_t* pair_out; /* [M] */
+  const int64_t* offs;     /* [K+1] device prefix of the group sizes */
+  int64_t offs_host[PCMI_MAX_KERNEL_VOLUME + 1];
+  int32_t mirror[PCMI_MAX_KERNEL_VOLUME]; /* offset_{mirror[k]} == -offset_k (stride 1) */
+} pcmi_kmap_t;
+
+/* Host-side enumeration of the kernel offsets in weight-slice order
+ * (ME.KernelGenerator, pc/model/modules/common.py:127-128,151-157).  out_host: [K,3]. */
+int pcmi_kernel_offsets(int kernel_size, int region, int32_t* out_host, int* K);
+/* kernel_size 3 / stride 1 (in_key == out_key) or kernel_size 2 / stride 2
+ * (out_key = strided key of in_key).  Cached; one stream sync on a miss (reads back the
+ * K+1 group offsets). */
+int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, int stride,
+                  int region, pcmi_kmap_t* out, pcmi_stream_t stream);
+/* Copy a map's tables into caller buffers (any may be NULL): nbr [K*n_out], pair_in [M],
+ * pair_out [M].  For parity checks and ME-style get_kernel_map(); not on the hot path. */
+int pcmi_kmap_export(const pcmi_kmap_t* map, int32_t* nbr, int32_t* pair_in, int32_t* pair_out,
+                     pcmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution -- replaces MEB.Convolution{Forward,Backward}GPU and
+ * ConvolutionTranspose{Forward,Backward}GPU (pc/model/modules/common.py:117-168; 63 modules
+ * in Res16UNet34C).  weight is [K, cin, cout] fp32 (K == 1: [cin, cout], map == NULL: the
+ * dense 1x1 "use_mm" path).  transpose == 0: conv along the map (in = map.n_in rows,
+ * out = map.n_out rows).  transpose == 1: transposed conv (in = map.n_out rows,
+ * out = map.n_in rows, same weight-slice index).
+ *   fwd        out[j]  = sum_k in[i] @ W[k]      (+ bias)
+ *   bwd_data   gin[i]  = sum_k gout[j] @ W[k]^T
+ *   bwd_weight gW[k]   = sum_pairs in[i]^T gout[j]
+ * All three overwrite their outputs (no accumulate) and are deterministic (no float atomics).
+ * ------------------------------------------------------------------------------------------ */
+size_t pcmi_spconv_workspace_bytes(int64_t n_in, int64_t n_out, int cin, int cout, int K,
+                                   int64_t M);
+int pcmi_spconv_fwd(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight,
+                    int cout, const pcmi_kmap_t* map, int transpose, const float* bias,
+                    float* out, int64_t out_ld, int64_t n_out, void* ws, size_t ws_bytes,
+                    pcmi_stream_t stream);
+int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout,
+                         const float* weight, int cin, const pcmi_kmap_t* map, int transpose,
+                         float* gin, int64_t gin_ld, int64_t n_in, void* ws, size_t ws_bytes,
+                         pcmi_stream_t stream);
+int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin,
+                           const float* gout, int64_t gout_ld, int64_t n_out, int cout,
+                           const pcmi_kmap_t* map, int transpose, float* gweight,
+                           float* gbias /* nullable [cout] */, void* ws, size_t ws_bytes,
+                           pcmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation / elementwise
+ *   BatchNorm1d inside ME.MinkowskiBatchNorm      pc/model/modules/common.py:19-21
+ *   MinkowskiReLU, `out += residual`              pc/model/modules/resnet_block.py:41,57
+ *   L2 row normalisation of the output features   pc/model/res16unet.py:262-266
+ * bn_fwd_train: batch statistics over the n rows (biased var for normalisation, unbiased
+ * for the running estimate, as torch), y = relu?((x-mean)*invstd*gamma+beta (+ residual)).
+ * bn_bwd: gradients of that fused expression; relu_mask_y (nullable) is the forward output
+ * whose sign gives the ReLU mask; dres (nullable) receives the residual-branch gradient.
+ * ------------------------------------------------------------------------------------------ */
+size_t pcmi_bn_workspace_bytes(int64_t n, int c);
+int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, const float* residual, int64_t res_ld, int relu,
+                      float* y, int64_t y_ld, float* save_mean, float* save_invstd, void* ws,
+                      size_t ws_bytes, pcmi_stream_t stream);
+int pcmi_bn_fwd_eval(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma,
+                     const float* beta, const float* running_mean, const float* running_var,
+                     float eps, const float* residual, int64_t res_ld, int relu, float* y,
+                     int64_t y_ld, pcmi_stream_t stream);
+int pcmi_bn_bwd(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld,
+                const float* relu_mask_y, int64_t y_ld, int64_t n, int c, const float* gamma,
+                const float* save_mean, const float* save_invstd, float* dx, int64_t dx_ld,
+                float* dres, int64_t dres_ld, float* dgamma, float* dbeta, void* ws,
+                size_t ws_bytes, pcmi_stream_t stream);
+int pcmi_relu_fwd(const float* x, int64_t x_ld, int64_t n, int c, float* y, int64_t y_ld,
+                  pcmi_stream_t stream);
+int pcmi_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int64_t n, int c,
+                  float* dx, int64_t dx_ld, pcmi_stream_t stream);
+int pcmi_add(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t n, int c,
+             float* y, int64_t y_ld, pcmi_stream_t stream);
+int pcmi_l2norm_fwd(const float* x, int64_t x_ld, int64_t n, int c, float* y, int64_t y_ld,
+                    float* norm /* [n] */, pcmi_stream_t stream);
+int pcmi_l2norm_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld,
+                    const float* norm, int64_t n, int c, float* dx, int64_t dx_ld,
+                    pcmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row gather / scatter-add used by the losses (F0[q_idx], pc/lib/ddp_trainer.py:209-213,409-410)
+ * scatter_add accumulates into dst (caller zero-fills); duplicate indices are summed.
+ * ------------------------------------------------------------------------------------------ */
+int pcmi_gather_rows(const float* src, int64_t src_ld, const int64_t* idx, int64_t n, int c,
+                     float* dst, int64_t dst_ld, pcmi_stream_t stream);
+int pcmi_scatter_add_rows(const float* src, int64_t src_ld, const int64_t* idx, int64_t n, int c,
+                          float* dst, int64_t dst_ld, pcmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PointInfoNCE block -- replaces torch.mm + nn.CrossEntropyLoss
+ * (pc/lib/ddp_trainer.py:419-426, pc/lib/criterion.py:13-18):
+ *   loss = mean_i( logsumexp_j(q_i.k_j / T) - q_i.k_i / T ),  q, k: [n, c] fp32.
+ * The n x n logits are never materialised.  fwd writes lse[n] and *loss (device scalar);
+ * bwd writes dq, dk for upstream gradient gscale (device scalar, nullable -> 1).
+ * ------------------------------------------------------------------------------------------ */
+size_t pcmi_nce_workspace_bytes(int64_t n, int c);
+int pcmi_nce_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, float* lse,
+                 float* loss, void* ws, size_t ws_bytes, pcmi_stream_t stream);
+int pcmi_nce_bwd(const float* q, const float* k, const float* lse, int64_t n, int c, float inv_T,
+                 const float* gscale, float* dq, float* dk, void* ws, size_t ws_bytes,
+                 pcmi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hardest-contrastive block (pc/lib/ddp_trainer.py:182-238)
+ *   pdist_argmin: dmin[p] = min_s sqrt(|a_p - b_s|^2 + 1e-7), amin[p] = first arg min
+ *                 (replaces pdist :182-184 + .min(1) :218-219; no [P,S,C] temporary)
+ *   keyset: device hash set of int64 keys a + b*M (replaces _hash :39-51 + np.isin :231-234)
+ *   hardest_loss: pos = mean(relu(|a-b|^2 - pos_thresh)); neg = (mean_masked(relu(nt-D01)^2)
+ *                 + mean_masked(relu(nt-D10)^2)) / 2 (fwd), and the gradients w.r.t. the four
+ *                 gathered matrices (bwd).
+ * ------------------------------------------------------------------------------------------ */
+int pcmi_pdist_argmin(const float* a, int64_t p, const float* b, int64_t s, int c, float* dmin,
+                      int32_t* amin, pcmi_stream_t stream);
+size_t pcmi_keyset_bytes(int64_t n_keys);
+int pcmi_keyset_build(const int32_t* pairs /* [n,2] */, int64_t n, int64_t M, void* set,
+                      size_t set_bytes, pcmi_stream_t stream);
+/* mask[p] = 1 iff (a[p] + b[p]*M) is NOT in the set (i.e. the mined negative is kept). */
+int pcmi_keyset_mask_absent(const void* set, size_t set_bytes, const int64_t* a, const int64_t* b,
+                            int64_t n, int64_t M, uint8_t* mask, pcmi_stream_t stream);
+int pcmi_hardest_loss_fwd(const float* posF0, const float* posF1, int64_t p, int c,
+                          const float* d01min, const uint8_t* mask0, const float* d10min,
+                          const uint8_t* mask1, float pos_thresh, float neg_thresh,
+                          float* losses /* [2]: pos, neg */, float* stats /* [5], for bwd */,
+                          void* ws, size_t ws_bytes, pcmi_stream_t stream);
+/* gl: device [2] upstream gradients of (pos, neg).  dsub* are accumulated (caller zero-fills). */
+int pcmi_hardest_loss_bwd(const float* posF0, const float* posF1, int64_t p, const float* subF0,
+                          const float* subF1, int c, const float* d01min, const int32_t* d01ind,
+                          const uint8_t* mask0, const float* d10min, const int32_t* d10ind,
+                          const uint8_t* mask1, float pos_thresh, float neg_thresh,
+                          const float* stats, const float* gl, float* dposF0, float* dposF1,
+                          float* dsubF0, float* dsubF1, pcmi_stream_t stream);
+size_t pcmi_hardest_workspace_bytes(int64_t p);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser -- replaces torch.optim.SGD.step (pc/lib/ddp_trainer.py:107-111,319,435) on a
+ * flat fp32 buffer:  g = grad_scale*g + wd*w;  v = mu*v + g;  w -= lr*v.
+ * (dampening 0, no Nesterov; a zero-filled v reproduces torch's first-step buffer init.)
+ * ------------------------------------------------------------------------------------------ */
+int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum,
+                  float weight_decay, float grad_scale, pcmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCMI_H_ */

@@ -1,0 +1,74 @@
+"""Builds libpcmi.so (HIP kernels + C ABI, gfx950 only) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container as well
+as on the GPU box.  Objects go to pointcontrast_amd/csrc/_build/, the library to
+pointcontrast_amd/libpcmi.so (git-ignored, but it travels with gpurun).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(CSRC, "_build")
+LIB = os.path.join(HERE, "libpcmi.so")
+SOURCES = ["coords.hip", "spconv.hip", "spconv_wgrad.hip", "norm.hip", "loss.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+  for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+    if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+      return c
+  raise RuntimeError("hipcc not found")
+
+
+def _digest(paths):
+  h = hashlib.sha256()
+  for p in paths:
+    with open(p, "rb") as f:
+      h.update(f.read())
+  h.update(" ".join(FLAGS).encode())
+  return h.hexdigest()
+
+
+def build_lib(force=False, verbose=False):
+  os.makedirs(BUILD, exist_ok=True)
+  headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "pcmi.h")]
+  hipcc = _hipcc()
+
+  def compile_one(src):
+    s = os.path.join(CSRC, src)
+    o = os.path.join(BUILD, src.replace(".hip", ".o"))
+    stamp = o + ".sha"
+    dig = _digest([s] + headers)
+    if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == dig:
+      return o, False
+    cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+      f.write(dig)
+    return o, True
+
+  with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+    results = list(ex.map(compile_one, SOURCES))
+  objs = [o for o, _ in results]
+  if force or any(ch for _, ch in results) or not os.path.exists(LIB):
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+      raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+  return LIB
+
+
+if __name__ == "__main__":
+  print(build_lib(force="--force" in sys.argv, verbose=True))

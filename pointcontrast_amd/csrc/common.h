@@ -1,0 +1,63 @@
+// Shared host/device helpers of libpcmi (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pcmi.h"
+
+namespace pcmi {
+
+void set_error(const char* fmt, ...);
+
+#define PCMI_HIP_CHECK(expr)                                                             \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      pcmi::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return PCMI_ERR_HIP;                                                               \
+    }                                                                                    \
+  } while (0)
+
+#define PCMI_REQUIRE(cond, code, ...)  \
+  do {                                 \
+    if (!(cond)) {                     \
+      pcmi::set_error(__VA_ARGS__);    \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define PCMI_LAUNCH_CHECK() PCMI_HIP_CHECK(hipGetLastError())
+
+static inline hipStream_t as_stream(pcmi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ---- packed coordinate key ---------------------------------------------------------------
+// (batch:10 | x:18 | y:18 | z:18), x/y/z biased by 2^17.  All-ones is the empty sentinel.
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr int kCoordBias = 1 << 17;
+
+__host__ __device__ inline uint64_t pack_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint32_t)b << 54) | ((uint64_t)(uint32_t)(x + kCoordBias) << 36) |
+         ((uint64_t)(uint32_t)(y + kCoordBias) << 18) | (uint64_t)(uint32_t)(z + kCoordBias);
+}
+
+__host__ __device__ inline uint32_t hash_key(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// floor division by a positive power-of-two-free divisor (coordinates may be negative)
+__host__ __device__ inline int floor_div(int a, int d) {
+  int q = a / d;
+  return (a % d != 0 && ((a < 0) != (d < 0))) ? q - 1 : q;
+}
+
+}  // namespace pcmi

@@ -1,0 +1,622 @@
+// Contrastive-loss blocks, row gather/scatter, and the fused SGD step.
+//
+//  * PointInfoNCE: the n x n logits q.k^T/T are produced tile by tile (64 x 64 per
+//    workgroup step, 4 x 4 per lane out of LDS), consumed by an online log-sum-exp and never
+//    written to memory; row reductions run across the 16 lanes that share a row
+//    (__shfl_xor inside a quarter wave).  The backward recomputes the tile and contracts it
+//    with the other operand out of LDS.
+//  * Hardest-contrastive: the [P, S] distance matrix is likewise only ever a register tile;
+//    min / arg-min are reduced across the quarter wave; the false-negative filter is a device
+//    hash set of int64 pair keys.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pcmi {
+
+constexpr int kTile = 64;
+
+// load a [64 x C] tile of `m` starting at row r0 (zero padded) into d-major LDS: s[d][row]
+template <int C>
+__device__ inline void load_tile_dmajor(const float* __restrict__ m, int64_t n, int64_t r0,
+                                        float (*s)[kTile + 4], int t) {
+  for (int e = t; e < kTile * (C / 4); e += 256) {
+    const int row = e / (C / 4), c4 = e % (C / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < n) v = *reinterpret_cast<const float4*>(m + (r0 + row) * C + c4 * 4);
+    s[c4 * 4 + 0][row] = v.x;
+    s[c4 * 4 + 1][row] = v.y;
+    s[c4 * 4 + 2][row] = v.z;
+    s[c4 * 4 + 3][row] = v.w;
+  }
+}
+
+template <int C>
+__device__ inline void load_tile_rowmajor(const float* __restrict__ m, int64_t n, int64_t r0,
+                                          float (*s)[C + 4], int t) {
+  for (int e = t; e < kTile * (C / 4); e += 256) {
+    const int row = e / (C / 4), c4 = e % (C / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < n) v = *reinterpret_cast<const float4*>(m + (r0 + row) * C + c4 * 4);
+    *reinterpret_cast<float4*>(&s[row][c4 * 4]) = v;
+  }
+}
+
+// 4x4 register tile of A_tile . B_tile^T from d-major LDS tiles
+template <int C>
+__device__ inline void dot_tile(const float (*sa)[kTile + 4], const float (*sb)[kTile + 4], int tr, int tc,
+                                float acc[4][4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 8
+  for (int d = 0; d < C; ++d) {
+    const float4 a = *reinterpret_cast<const float4*>(&sa[d][tr * 4]);
+    const float4 b = *reinterpret_cast<const float4*>(&sb[d][tc * 4]);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+  }
+}
+
+// ---- NCE forward: lse[i], per-block partial of sum_i (lse_i - s_ii) -----------------------------
+template <int C>
+__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      int64_t n, float inv_T, float* __restrict__ lse,
+                                                      float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float sq[C][kTile + 4];
+  __shared__ __attribute__((aligned(16))) float sk[C][kTile + 4];
+  __shared__ float s_part[4];
+  const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+  const int64_t r0 = (int64_t)blockIdx.x * kTile;
+  load_tile_dmajor<C>(q, n, r0, sq, t);
+  float m[4], l[4], diag[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m[i] = -INFINITY;
+    l[i] = 0.f;
+    diag[i] = 0.f;
+  }
+  for (int64_t c0 = 0; c0 < n; c0 += kTile) {
+    __syncthreads();
+    load_tile_dmajor<C>(k, n, c0, sk, t);
+    __syncthreads();
+    float acc[4][4];
+    dot_tile<C>(sq, sk, tr, tc, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = c0 + tc * 4 + j;
+        const float s = acc[i][j] * inv_T;
+        acc[i][j] = s;
+        if (col < n) tmax = fmaxf(tmax, s);
+        if (col == r0 + tr * 4 + i) diag[i] = s;
+      }
+      if (tmax > m[i]) {
+        l[i] *= expf(m[i] - tmax);
+        m[i] = tmax;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + tc * 4 + j < n) l[i] += expf(acc[i][j] - m[i]);
+    }
+  }
+  // combine the 16 lanes that share the rows
+  float contrib = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const float om = __shfl_xor(m[i], d, 64), ol = __shfl_xor(l[i], d, 64);
+      const float nm = fmaxf(m[i], om);
+      l[i] = (m[i] == -INFINITY ? 0.f : l[i] * expf(m[i] - nm)) + (om == -INFINITY ? 0.f : ol * expf(om - nm));
+      m[i] = nm;
+      diag[i] += __shfl_xor(diag[i], d, 64);
+    }
+    const int64_t row = r0 + tr * 4 + i;
+    if (row < n) {
+      const float v = m[i] + logf(l[i]);
+      if (tc == 0) {
+        lse[row] = v;
+        contrib += v - diag[i];
+      }
+    }
+  }
+  // block sum of contrib (only tc == 0 lanes hold something)
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) contrib += __shfl_xor(contrib, d, 64);
+  if ((t & 63) == 0) s_part[t >> 6] = contrib;
+  __syncthreads();
+  if (t == 0) part[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ void sum_scale_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    *out = s * scale;
+  }
+}
+
+// ---- NCE backward: d_own[a] = gs * sum_b (softmax - I)[.,.] other_b ------------------------------
+// FOR_K == false: own = q (rows a = i), other = k;   p = exp(s_ab - lse[a])
+// FOR_K == true : own = k (rows a = j), other = q;   p = exp(s_ab - lse[b])
+template <int C, bool FOR_K>
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ own, const float* __restrict__ other,
+                                                      const float* __restrict__ lse, int64_t n, float inv_T,
+                                                      const float* __restrict__ gscale, float* __restrict__ d_own) {
+  __shared__ __attribute__((aligned(16))) float so[C][kTile + 4];
+  __shared__ __attribute__((aligned(16))) float sx[C][kTile + 4];
+  __shared__ __attribute__((aligned(16))) float sxr[kTile][C + 4];
+  __shared__ float sw[kTile][kTile + 1];
+  const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+  const int64_t r0 = (int64_t)blockIdx.x * kTile;
+  const float gs = (gscale ? *gscale : 1.f) * inv_T / (float)n;
+  load_tile_dmajor<C>(own, n, r0, so, t);
+  // second-GEMM mapping: thread -> (row, CD consecutive channels)
+  constexpr int TPR = 4;  // threads per row
+  constexpr int CD = C / TPR;
+  const int orow = t / TPR, od0 = (t % TPR) * CD;
+  float dacc[CD];
+#pragma unroll
+  for (int d = 0; d < CD; ++d) dacc[d] = 0.f;
+  float lse_own[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lse_own[i] = (!FOR_K && r0 + tr * 4 + i < n) ? lse[r0 + tr * 4 + i] : 0.f;
+  for (int64_t c0 = 0; c0 < n; c0 += kTile) {
+    __syncthreads();
+    load_tile_dmajor<C>(other, n, c0, sx, t);
+    load_tile_rowmajor<C>(other, n, c0, sxr, t);
+    __syncthreads();
+    float acc[4][4];
+    dot_tile<C>(so, sx, tr, tc, acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t b = c0 + tc * 4 + j;
+      const float lse_b = (FOR_K && b < n) ? lse[b] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t a = r0 + tr * 4 + i;
+        float w = 0.f;
+        if (a < n && b < n) {
+          const float p = expf(acc[i][j] * inv_T - (FOR_K ? lse_b : lse_own[i]));
+          w = (p - (a == b ? 1.f : 0.f)) * gs;
+        }
+        sw[tr * 4 + i][tc * 4 + j] = w;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int b = 0; b < kTile; ++b) {
+      const float w = sw[orow][b];
+#pragma unroll
+      for (int d = 0; d < CD; ++d) dacc[d] = fmaf(w, sxr[b][od0 + d], dacc[d]);
+    }
+  }
+  if (r0 + orow < n) {
+#pragma unroll
+    for (int d = 0; d < CD; ++d) d_own[(r0 + orow) * C + od0 + d] = dacc[d];
+  }
+}
+
+// ---- pdist + argmin ------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void pdist_argmin_kernel(const float* __restrict__ a, int64_t p,
+                                                           const float* __restrict__ b, int64_t s,
+                                                           float* __restrict__ dmin, int32_t* __restrict__ amin) {
+  __shared__ __attribute__((aligned(16))) float sa[C][kTile + 4];
+  __shared__ __attribute__((aligned(16))) float sb[C][kTile + 4];
+  const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+  const int64_t r0 = (int64_t)blockIdx.x * kTile;
+  load_tile_dmajor<C>(a, p, r0, sa, t);
+  float best[4];
+  int32_t bidx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    best[i] = INFINITY;
+    bidx[i] = 0x7fffffff;
+  }
+  for (int64_t c0 = 0; c0 < s; c0 += kTile) {
+    __syncthreads();
+    load_tile_dmajor<C>(b, s, c0, sb, t);
+    __syncthreads();
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < C; ++d) {
+      const float4 av4 = *reinterpret_cast<const float4*>(&sa[d][tr * 4]);
+      const float4 bv4 = *reinterpret_cast<const float4*>(&sb[d][tc * 4]);
+      const float av[4] = {av4.x, av4.y, av4.z, av4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float df = av[i] - bv[j];
+          acc[i][j] = fmaf(df, df, acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = c0 + tc * 4 + j;
+        if (col < s && acc[i][j] < best[i]) {
+          best[i] = acc[i][j];
+          bidx[i] = (int32_t)col;
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const float ob = __shfl_xor(best[i], d, 64);
+      const int32_t oi = __shfl_xor(bidx[i], d, 64);
+      if (ob < best[i] || (ob == best[i] && oi < bidx[i])) {
+        best[i] = ob;
+        bidx[i] = oi;
+      }
+    }
+    const int64_t row = r0 + tr * 4 + i;
+    if (row < p && tc == 0) {
+      dmin[row] = sqrtf(best[i] + 1e-7f);
+      amin[row] = bidx[i];
+    }
+  }
+}
+
+// ---- int64 key set ---------------------------------------------------------------------------------
+__global__ void keyset_build_kernel(const int32_t* __restrict__ pairs, int64_t n, int64_t M, uint64_t* keys,
+                                    uint32_t mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = (uint64_t)((int64_t)pairs[2 * i] + (int64_t)pairs[2 * i + 1] * M);
+  uint32_t slot = hash_key(key) & mask;
+  while (true) {
+    const unsigned long long prev =
+        atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) return;
+    slot = (slot + 1) & mask;
+  }
+}
+
+__global__ void keyset_mask_kernel(const uint64_t* __restrict__ keys, uint32_t mask, const int64_t* __restrict__ a,
+                                   const int64_t* __restrict__ b, int64_t n, int64_t M, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = (uint64_t)(a[i] + b[i] * M);
+  uint32_t slot = hash_key(key) & mask;
+  uint8_t absent = 1;
+  while (true) {
+    const uint64_t kk = keys[slot];
+    if (kk == key) {
+      absent = 0;
+      break;
+    }
+    if (kk == kEmptyKey) break;
+    slot = (slot + 1) & mask;
+  }
+  out[i] = absent;
+}
+
+// ---- hardest-contrastive loss values + gradients ------------------------------------------------------
+// stats[0] = sum relu(|a-b|^2 - pt); [1] = sum_mask0 relu(nt - d01)^2; [2] = count mask0;
+// [3] = sum_mask1 relu(nt - d10)^2; [4] = count mask1
+__global__ __launch_bounds__(256) void hardest_stats_kernel(const float* __restrict__ f0, const float* __restrict__ f1,
+                                                            int64_t p, int c, const float* __restrict__ d01,
+                                                            const uint8_t* __restrict__ m0,
+                                                            const float* __restrict__ d10,
+                                                            const uint8_t* __restrict__ m1, float pt, float nt,
+                                                            float* __restrict__ part /* [blocks][5] */) {
+  __shared__ float s_red[4][5];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < p) {
+    float d2 = 0.f;
+    for (int d = 0; d < c; ++d) {
+      const float df = f0[i * c + d] - f1[i * c + d];
+      d2 = fmaf(df, df, d2);
+    }
+    v[0] = fmaxf(d2 - pt, 0.f);
+    if (m0[i]) {
+      const float h = fmaxf(nt - d01[i], 0.f);
+      v[1] = h * h;
+      v[2] = 1.f;
+    }
+    if (m1[i]) {
+      const float h = fmaxf(nt - d10[i], 0.f);
+      v[3] = h * h;
+      v[4] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v[q] += __shfl_xor(v[q], d, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5)
+    part[(int64_t)blockIdx.x * 5 + threadIdx.x] =
+        s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+}
+
+__global__ void hardest_final_kernel(const float* __restrict__ part, int nblocks, int64_t p, float* __restrict__ stats,
+                                     float* __restrict__ losses) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nblocks; ++b)
+    for (int q = 0; q < 5; ++q) s[q] += part[b * 5 + q];
+  for (int q = 0; q < 5; ++q) stats[q] = s[q];
+  losses[0] = s[0] / (float)p;
+  losses[1] = (s[1] / s[2] + s[3] / s[4]) * 0.5f;
+}
+
+// one thread per (positive pair, channel)
+__global__ __launch_bounds__(256) void hardest_grad_kernel(
+    const float* __restrict__ f0, const float* __restrict__ f1, int64_t p, int c, const float* __restrict__ sub0,
+    const float* __restrict__ sub1, const float* __restrict__ d01, const int32_t* __restrict__ i01,
+    const uint8_t* __restrict__ m0, const float* __restrict__ d10, const int32_t* __restrict__ i10,
+    const uint8_t* __restrict__ m1, float pt, float nt, const float* __restrict__ stats,
+    const float* __restrict__ gl, float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ gsub0,
+    float* __restrict__ gsub1) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p * c) return;
+  const int64_t i = idx / c;
+  const int d = (int)(idx - i * c);
+  // positive term: every lane of the row recomputes |a-b|^2 (c is small)
+  float d2 = 0.f;
+  for (int e = 0; e < c; ++e) {
+    const float df = f0[i * c + e] - f1[i * c + e];
+    d2 = fmaf(df, df, d2);
+  }
+  const float a = f0[idx], b = f1[idx];
+  const float up_pos = gl[0], up_neg = gl[1];
+  float ga = 0.f, gb = 0.f;
+  if (d2 - pt > 0.f) {
+    const float gpos = up_pos * 2.f * (a - b) / (float)p;
+    ga += gpos;
+    gb -= gpos;
+  }
+  if (m0[i]) {
+    const float h = nt - d01[i];
+    if (h > 0.f) {
+      const int32_t q = i01[i];
+      const float coef = up_neg * -2.f * h / stats[2] * 0.5f;  // d neg / d D01
+      const float gd = coef * (a - sub1[(int64_t)q * c + d]) / d01[i];
+      ga += gd;
+      atomicAdd(&gsub1[(int64_t)q * c + d], -gd);
+    }
+  }
+  if (m1[i]) {
+    const float h = nt - d10[i];
+    if (h > 0.f) {
+      const int32_t q = i10[i];
+      const float coef = up_neg * -2.f * h / stats[4] * 0.5f;
+      const float gd = coef * (b - sub0[(int64_t)q * c + d]) / d10[i];
+      gb += gd;
+      atomicAdd(&gsub0[(int64_t)q * c + d], -gd);
+    }
+  }
+  g0[idx] = ga;
+  g1[idx] = gb;
+}
+
+// ---- rows gather / scatter-add ------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_ld, const int64_t* __restrict__ idx,
+                                   int64_t n, int c4, float* __restrict__ dst, int64_t dst_ld) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * c4) return;
+  const int64_t r = e / c4;
+  const int col = (int)(e - r * c4);
+  *reinterpret_cast<float4*>(dst + r * dst_ld + col * 4) =
+      *reinterpret_cast<const float4*>(src + idx[r] * src_ld + col * 4);
+}
+
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t src_ld, const int64_t* __restrict__ idx,
+                                        int64_t n, int c, float* __restrict__ dst, int64_t dst_ld) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * c) return;
+  const int64_t r = e / c;
+  const int col = (int)(e - r * c);
+  atomicAdd(dst + idx[r] * dst_ld + col, src[r * src_ld + col]);
+}
+
+// ---- SGD ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
+                                                  int64_t n, float lr, float mu, float wd, float gscale) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 wv = reinterpret_cast<float4*>(w)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    vv.x = mu * vv.x + (gscale * gv.x + wd * wv.x);
+    vv.y = mu * vv.y + (gscale * gv.y + wd * wv.y);
+    vv.z = mu * vv.z + (gscale * gv.z + wd * wv.z);
+    vv.w = mu * vv.w + (gscale * gv.w + wd * wv.w);
+    wv.x -= lr * vv.x;
+    wv.y -= lr * vv.y;
+    wv.z -= lr * vv.z;
+    wv.w -= lr * vv.w;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    reinterpret_cast<float4*>(w)[i] = wv;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    if (i < n) {
+      const float vv = mu * v[i] + (gscale * g[i] + wd * w[i]);
+      v[i] = vv;
+      w[i] -= lr * vv;
+    }
+  }
+}
+
+static uint32_t keyset_cap(size_t bytes) {
+  uint32_t cap = 1;
+  while ((size_t)cap * 2 * sizeof(uint64_t) <= bytes) cap <<= 1;
+  return cap;
+}
+
+}  // namespace pcmi
+
+using namespace pcmi;
+
+extern "C" {
+
+int pcmi_gather_rows(const float* src, int64_t src_ld, const int64_t* idx, int64_t n, int c, float* dst,
+                     int64_t dst_ld, pcmi_stream_t stream) {
+  PCMI_REQUIRE(src && idx && dst && c % 4 == 0 && src_ld % 4 == 0 && dst_ld % 4 == 0 && (uintptr_t)src % 16 == 0 &&
+                   (uintptr_t)dst % 16 == 0,
+               PCMI_ERR_INVALID, "gather_rows: bad argument");
+  if (n == 0) return PCMI_OK;
+  gather_rows_kernel<<<dim3((unsigned)ceil_div(n * (c / 4), 256)), 256, 0, as_stream(stream)>>>(src, src_ld, idx, n, c / 4, dst,
+                                                                                             dst_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_scatter_add_rows(const float* src, int64_t src_ld, const int64_t* idx, int64_t n, int c, float* dst,
+                          int64_t dst_ld, pcmi_stream_t stream) {
+  PCMI_REQUIRE(src && idx && dst && c > 0, PCMI_ERR_INVALID, "scatter_add_rows: bad argument");
+  if (n == 0) return PCMI_OK;
+  scatter_add_rows_kernel<<<dim3((unsigned)ceil_div(n * c, 256)), 256, 0, as_stream(stream)>>>(src, src_ld, idx, n, c, dst, dst_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+size_t pcmi_nce_workspace_bytes(int64_t n, int c) {
+  (void)c;
+  return (size_t)(ceil_div(n, kTile) + 1) * sizeof(float) + 256;
+}
+
+int pcmi_nce_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, float* lse, float* loss, void* ws,
+                 size_t ws_bytes, pcmi_stream_t stream) {
+  PCMI_REQUIRE(q && k && lse && loss && n > 0, PCMI_ERR_INVALID, "nce_fwd: bad argument");
+  PCMI_REQUIRE(c == 16 || c == 32, PCMI_ERR_UNSUPPORTED, "nce_fwd: feature width %d not in {16,32}", c);
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_nce_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "nce_fwd: workspace too small");
+  PCMI_REQUIRE((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0, PCMI_ERR_INVALID, "nce_fwd: q/k must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const int nb = (int)ceil_div(n, kTile);
+  float* part = (float*)ws;
+  if (c == 16) nce_fwd_kernel<16><<<nb, 256, 0, st>>>(q, k, n, inv_T, lse, part);
+  if (c == 32) nce_fwd_kernel<32><<<nb, 256, 0, st>>>(q, k, n, inv_T, lse, part);
+  PCMI_LAUNCH_CHECK();
+  sum_scale_kernel<<<1, 64, 0, st>>>(part, nb, 1.0f / (float)n, loss);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_nce_bwd(const float* q, const float* k, const float* lse, int64_t n, int c, float inv_T, const float* gscale,
+                 float* dq, float* dk, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  (void)ws;
+  (void)ws_bytes;
+  PCMI_REQUIRE(q && k && lse && dq && dk && n > 0, PCMI_ERR_INVALID, "nce_bwd: bad argument");
+  PCMI_REQUIRE(c == 16 || c == 32, PCMI_ERR_UNSUPPORTED, "nce_bwd: feature width %d not in {16,32}", c);
+  hipStream_t st = as_stream(stream);
+  const int nb = (int)ceil_div(n, kTile);
+#define PCMI_NCE_BWD(CC)                                                               \
+  nce_bwd_kernel<CC, false><<<nb, 256, 0, st>>>(q, k, lse, n, inv_T, gscale, dq);      \
+  nce_bwd_kernel<CC, true><<<nb, 256, 0, st>>>(k, q, lse, n, inv_T, gscale, dk);
+  if (c == 16) { PCMI_NCE_BWD(16) }
+  if (c == 32) { PCMI_NCE_BWD(32) }
+#undef PCMI_NCE_BWD
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_pdist_argmin(const float* a, int64_t p, const float* b, int64_t s, int c, float* dmin, int32_t* amin,
+                      pcmi_stream_t stream) {
+  PCMI_REQUIRE(a && b && dmin && amin && p > 0 && s > 0, PCMI_ERR_INVALID, "pdist_argmin: bad argument");
+  PCMI_REQUIRE(c == 16 || c == 32 || c == 64, PCMI_ERR_UNSUPPORTED, "pdist_argmin: feature width %d not in {16,32,64}", c);
+  hipStream_t st = as_stream(stream);
+  const int nb = (int)ceil_div(p, kTile);
+  if (c == 16) pdist_argmin_kernel<16><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  if (c == 32) pdist_argmin_kernel<32><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  if (c == 64) pdist_argmin_kernel<64><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+size_t pcmi_keyset_bytes(int64_t n_keys) {
+  size_t cap = 1024;
+  while ((int64_t)cap < 2 * n_keys) cap <<= 1;
+  return cap * sizeof(uint64_t);
+}
+
+int pcmi_keyset_build(const int32_t* pairs, int64_t n, int64_t M, void* set, size_t set_bytes, pcmi_stream_t stream) {
+  PCMI_REQUIRE(pairs && set && set_bytes >= pcmi_keyset_bytes(n), PCMI_ERR_WORKSPACE, "keyset_build: set buffer too small");
+  hipStream_t st = as_stream(stream);
+  const uint32_t cap = keyset_cap(set_bytes);
+  PCMI_HIP_CHECK(hipMemsetAsync(set, 0xFF, (size_t)cap * sizeof(uint64_t), st));
+  if (n > 0) {
+    keyset_build_kernel<<<dim3((unsigned)ceil_div(n, 256)), 256, 0, st>>>(pairs, n, M, (uint64_t*)set, cap - 1);
+    PCMI_LAUNCH_CHECK();
+  }
+  return PCMI_OK;
+}
+
+int pcmi_keyset_mask_absent(const void* set, size_t set_bytes, const int64_t* a, const int64_t* b, int64_t n, int64_t M,
+                            uint8_t* mask, pcmi_stream_t stream) {
+  PCMI_REQUIRE(set && a && b && mask, PCMI_ERR_INVALID, "keyset_mask_absent: bad argument");
+  if (n == 0) return PCMI_OK;
+  const uint32_t cap = keyset_cap(set_bytes);
+  keyset_mask_kernel<<<dim3((unsigned)ceil_div(n, 256)), 256, 0, as_stream(stream)>>>((const uint64_t*)set, cap - 1, a, b, n, M,
+                                                                                   mask);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+size_t pcmi_hardest_workspace_bytes(int64_t p) { return (size_t)(ceil_div(p, 256) * 5 + 8) * sizeof(float) + 256; }
+
+int pcmi_hardest_loss_fwd(const float* posF0, const float* posF1, int64_t p, int c, const float* d01min,
+                          const uint8_t* mask0, const float* d10min, const uint8_t* mask1, float pos_thresh,
+                          float neg_thresh, float* losses, float* stats, void* ws, size_t ws_bytes,
+                          pcmi_stream_t stream) {
+  PCMI_REQUIRE(posF0 && posF1 && d01min && mask0 && d10min && mask1 && losses && stats && p > 0 && c > 0, PCMI_ERR_INVALID,
+               "hardest_loss_fwd: bad argument");
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_hardest_workspace_bytes(p), PCMI_ERR_WORKSPACE, "hardest_loss_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int nb = (int)ceil_div(p, 256);
+  float* part = (float*)ws;
+  hardest_stats_kernel<<<nb, 256, 0, st>>>(posF0, posF1, p, c, d01min, mask0, d10min, mask1, pos_thresh, neg_thresh, part);
+  PCMI_LAUNCH_CHECK();
+  hardest_final_kernel<<<1, 64, 0, st>>>(part, nb, p, stats, losses);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_hardest_loss_bwd(const float* posF0, const float* posF1, int64_t p, const float* subF0, const float* subF1, int c,
+                          const float* d01min, const int32_t* d01ind, const uint8_t* mask0, const float* d10min,
+                          const int32_t* d10ind, const uint8_t* mask1, float pos_thresh, float neg_thresh,
+                          const float* stats, const float* gl, float* dposF0, float* dposF1, float* dsubF0,
+                          float* dsubF1, pcmi_stream_t stream) {
+  PCMI_REQUIRE(posF0 && posF1 && subF0 && subF1 && d01min && d01ind && mask0 && d10min && d10ind && mask1 && stats && gl &&
+                   dposF0 && dposF1 && dsubF0 && dsubF1 && p > 0 && c > 0,
+               PCMI_ERR_INVALID, "hardest_loss_bwd: bad argument");
+  hardest_grad_kernel<<<dim3((unsigned)ceil_div(p * c, 256)), 256, 0, as_stream(stream)>>>(
+      posF0, posF1, p, c, subF0, subF1, d01min, d01ind, mask0, d10min, d10ind, mask1, pos_thresh, neg_thresh, stats, gl,
+      dposF0, dposF1, dsubF0, dsubF1);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
+                  float grad_scale, pcmi_stream_t stream) {
+  PCMI_REQUIRE(w && g && v && n >= 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)v % 16 == 0,
+               PCMI_ERR_INVALID, "sgd_step: buffers must be 16-byte aligned");
+  if (n == 0) return PCMI_OK;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / 4, 256), 256 * 8));
+  sgd_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, g, v, n, lr, momentum, weight_decay, grad_scale);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// BatchNorm (training statistics over all rows of a [n, c] activation), fused ReLU / residual
+// epilogues, standalone ReLU / add, and the L2 row normalisation of the output features.
+// All of these are HBM-bound streaming kernels: float4 per lane, every lane of a wave on one
+// contiguous run of a row, per-channel reductions done in two deterministic levels
+// (per-block partials in registers + LDS, then one thread per channel combining the blocks
+// with Chan's parallel-variance update).
+#include <algorithm>
+
+#include "common.h"
+
+namespace pcmi {
+
+constexpr int kMaxRedBlocks = 1024;
+
+struct RedGeom {
+  int c4;              // float4 columns
+  int rp;              // row lanes per block (256 / c4)
+  int rows_per_block;  // multiple of rp
+  int nblocks;
+};
+
+static RedGeom red_geom(int64_t n, int c) {
+  RedGeom g;
+  g.c4 = c / 4;
+  g.rp = 256 / g.c4;
+  int64_t rpb = std::max<int64_t>((int64_t)g.rp * 16, ceil_div(n, kMaxRedBlocks));
+  rpb = ceil_div(rpb, g.rp) * g.rp;
+  g.rows_per_block = (int)rpb;
+  g.nblocks = (int)std::max<int64_t>(1, ceil_div(n, rpb));
+  return g;
+}
+
+// MODE 0: (sum x, sum x^2) per block -> (mean_b, M2_b)
+// MODE 1: (sum dy_eff, sum dy_eff * xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld,
+    const float* __restrict__ ymask, int64_t y_ld, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int64_t n, int c4, int rp, int rows_per_block,
+    float* __restrict__ part /* [nblocks][2][c] */) {
+  __shared__ float4 s_a[256];
+  __shared__ float4 s_b[256];
+  const int t = threadIdx.x;
+  const int col = t % c4, rl = t / c4;
+  const int c = c4 * 4;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + (int64_t)rows_per_block, n);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (rl < rp) {
+    float4 mu = a, is = a;
+    if (MODE == 1) {
+      mu = reinterpret_cast<const float4*>(mean)[col];
+      is = reinterpret_cast<const float4*>(invstd)[col];
+    }
+    for (int64_t r = r0 + rl; r < r1; r += rp) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
+      if (MODE == 0) {
+        a.x += xv.x; a.y += xv.y; a.z += xv.z; a.w += xv.w;
+        b.x = fmaf(xv.x, xv.x, b.x); b.y = fmaf(xv.y, xv.y, b.y);
+        b.z = fmaf(xv.z, xv.z, b.z); b.w = fmaf(xv.w, xv.w, b.w);
+      } else {
+        float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
+        if (ymask) {
+          const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
+          g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+          g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        b.x = fmaf(g.x, (xv.x - mu.x) * is.x, b.x); b.y = fmaf(g.y, (xv.y - mu.y) * is.y, b.y);
+        b.z = fmaf(g.z, (xv.z - mu.z) * is.z, b.z); b.w = fmaf(g.w, (xv.w - mu.w) * is.w, b.w);
+      }
+    }
+  }
+  s_a[t] = a;
+  s_b[t] = b;
+  __syncthreads();
+  if (t < c4) {
+    float4 sa = s_a[t], sb = s_b[t];
+    for (int q = 1; q < rp; ++q) {
+      const float4 va = s_a[q * c4 + t], vb = s_b[q * c4 + t];
+      sa.x += va.x; sa.y += va.y; sa.z += va.z; sa.w += va.w;
+      sb.x += vb.x; sb.y += vb.y; sb.z += vb.z; sb.w += vb.w;
+    }
+    float* p0 = part + (int64_t)blockIdx.x * 2 * c;
+    if (MODE == 0) {
+      const float nb = (float)(r1 - r0);
+      float4 m, m2;
+      m.x = sa.x / nb; m.y = sa.y / nb; m.z = sa.z / nb; m.w = sa.w / nb;
+      m2.x = fmaxf(sb.x - sa.x * m.x, 0.f); m2.y = fmaxf(sb.y - sa.y * m.y, 0.f);
+      m2.z = fmaxf(sb.z - sa.z * m.z, 0.f); m2.w = fmaxf(sb.w - sa.w * m.w, 0.f);
+      reinterpret_cast<float4*>(p0)[t] = m;
+      reinterpret_cast<float4*>(p0 + c)[t] = m2;
+    } else {
+      reinterpret_cast<float4*>(p0)[t] = sa;
+      reinterpret_cast<float4*>(p0 + c)[t] = sb;
+    }
+  }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblocks, int64_t n, int c,
+                                      int rows_per_block, float eps, float momentum,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var,
+                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int b = 0; b < nblocks; ++b) {
+    const int64_t r0 = (int64_t)b * rows_per_block;
+    const float nb = (float)(min(r0 + (int64_t)rows_per_block, n) - r0);
+    const float mb = part[(int64_t)b * 2 * c + ch], m2b = part[(int64_t)b * 2 * c + c + ch];
+    const float tot = cnt + nb;
+    const float delta = mb - mean;
+    mean += delta * (nb / tot);
+    m2 += m2b + delta * delta * (cnt * nb / tot);
+    cnt = tot;
+  }
+  const float var = m2 / cnt;
+  save_mean[ch] = mean;
+  save_invstd[ch] = 1.0f / sqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = cnt > 1.f ? m2 / (cnt - 1.f) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+  }
+}
+
+__global__ void colsum2_final_kernel(const float* __restrict__ part, int nblocks, int c,
+                                     float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float a = 0.f, b = 0.f;
+  for (int q = 0; q < nblocks; ++q) {
+    a += part[(int64_t)q * 2 * c + ch];
+    b += part[(int64_t)q * 2 * c + c + ch];
+  }
+  out_a[ch] = a;
+  out_b[ch] = b;
+}
+
+// y = relu?( (x - mean) * (invstd * gamma) + beta (+ residual) )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                       int64_t n, int c4, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd_or_var, float eps,
+                                                       int use_var, const float* __restrict__ res,
+                                                       int64_t res_ld, int relu, float* __restrict__ y,
+                                                       int64_t y_ld) {
+  const int64_t total = n * c4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / c4;
+    const int col = (int)(idx - r * c4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
+    const float4 mu = reinterpret_cast<const float4*>(mean)[col];
+    float4 is = reinterpret_cast<const float4*>(invstd_or_var)[col];
+    if (use_var) {
+      is.x = 1.0f / sqrtf(is.x + eps); is.y = 1.0f / sqrtf(is.y + eps);
+      is.z = 1.0f / sqrtf(is.z + eps); is.w = 1.0f / sqrtf(is.w + eps);
+    }
+    const float4 g = reinterpret_cast<const float4*>(gamma)[col];
+    const float4 b = reinterpret_cast<const float4*>(beta)[col];
+    float4 o;
+    o.x = (xv.x - mu.x) * is.x * g.x + b.x;
+    o.y = (xv.y - mu.y) * is.y * g.y + b.y;
+    o.z = (xv.z - mu.z) * is.z * g.z + b.z;
+    o.w = (xv.w - mu.w) * is.w * g.w + b.w;
+    if (res) {
+      const float4 rv = *reinterpret_cast<const float4*>(res + r * res_ld + col * 4);
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(y + r * y_ld + col * 4) = o;
+  }
+}
+
+// dx = gamma * invstd * (g - sum_g/n - xhat * sum_gx/n),  dres = g   (g = relu-masked dy)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t x_ld,
+    const float* __restrict__ ymask, int64_t y_ld, int64_t n, int c4, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ sum_g,
+    const float* __restrict__ sum_gx, float* __restrict__ dx, int64_t dx_ld, float* __restrict__ dres,
+    int64_t dres_ld) {
+  const int64_t total = n * c4;
+  const float inv_n = 1.0f / (float)n;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / c4;
+    const int col = (int)(idx - r * c4);
+    float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
+    if (ymask) {
+      const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
+    const float4 mu = reinterpret_cast<const float4*>(mean)[col];
+    const float4 is = reinterpret_cast<const float4*>(invstd)[col];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
+    const float4 sg = reinterpret_cast<const float4*>(sum_g)[col];
+    const float4 sx = reinterpret_cast<const float4*>(sum_gx)[col];
+    float4 o;
+    o.x = ga.x * is.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * is.x * sx.x * inv_n);
+    o.y = ga.y * is.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * is.y * sx.y * inv_n);
+    o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
+    o.w = ga.w * is.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * is.w * sx.w * inv_n);
+    *reinterpret_cast<float4*>(dx + r * dx_ld + col * 4) = o;
+    if (dres) *reinterpret_cast<float4*>(dres + r * dres_ld + col * 4) = g;
+  }
+}
+
+// OP 0: y = max(a, 0); OP 1: y = b > 0 ? a : 0 (a = dy, b = y); OP 2: y = a + b
+template <int OP>
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, int64_t a_ld,
+                                                      const float* __restrict__ b, int64_t b_ld, int64_t n,
+                                                      int c4, float* __restrict__ y, int64_t y_ld) {
+  const int64_t total = n * c4;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / c4;
+    const int col = (int)(idx - r * c4);
+    const float4 av = *reinterpret_cast<const float4*>(a + r * a_ld + col * 4);
+    float4 o;
+    if (OP == 0) {
+      o = make_float4(fmaxf(av.x, 0.f), fmaxf(av.y, 0.f), fmaxf(av.z, 0.f), fmaxf(av.w, 0.f));
+    } else {
+      const float4 bv = *reinterpret_cast<const float4*>(b + r * b_ld + col * 4);
+      if (OP == 1)
+        o = make_float4(bv.x > 0.f ? av.x : 0.f, bv.y > 0.f ? av.y : 0.f, bv.z > 0.f ? av.z : 0.f,
+                        bv.w > 0.f ? av.w : 0.f);
+      else
+        o = make_float4(av.x + bv.x, av.y + bv.y, av.z + bv.z, av.w + bv.w);
+    }
+    *reinterpret_cast<float4*>(y + r * y_ld + col * 4) = o;
+  }
+}
+
+// L2 row normalisation: LPR lanes per row (power of two >= c/4), float4 per lane
+template <bool BWD>
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a, int64_t a_ld,
+                                                     const float* __restrict__ yin, int64_t y_ld,
+                                                     float* __restrict__ norm, int64_t n, int c4, int lpr,
+                                                     float* __restrict__ out, int64_t out_ld) {
+  const int rows_per_block = 256 / lpr;
+  const int sub = threadIdx.x % lpr;
+  const int64_t r = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / lpr;
+  const bool active = r < n && sub < c4;
+  float4 av = make_float4(0.f, 0.f, 0.f, 0.f), yv = av;
+  if (active) {
+    av = *reinterpret_cast<const float4*>(a + r * a_ld + sub * 4);
+    if (BWD) yv = *reinterpret_cast<const float4*>(yin + r * y_ld + sub * 4);
+  }
+  float s = BWD ? (av.x * yv.x + av.y * yv.y + av.z * yv.z + av.w * yv.w)
+                : (av.x * av.x + av.y * av.y + av.z * av.z + av.w * av.w);
+  for (int d = 1; d < lpr; d <<= 1) s += __shfl_xor(s, d, 64);
+  if (!active) return;
+  float4 o;
+  if (!BWD) {
+    const float nr = sqrtf(s);
+    o = make_float4(av.x / nr, av.y / nr, av.z / nr, av.w / nr);
+    if (sub == 0) norm[r] = nr;
+  } else {
+    const float nr = norm[r];
+    o = make_float4((av.x - yv.x * s) / nr, (av.y - yv.y * s) / nr, (av.z - yv.z * s) / nr,
+                    (av.w - yv.w * s) / nr);
+  }
+  *reinterpret_cast<float4*>(out + r * out_ld + sub * 4) = o;
+}
+
+static int check_rows(const char* who, const void* p, int64_t ld, int c) {
+  PCMI_REQUIRE(p && c > 0 && c % 4 == 0 && c <= 1024 && ld % 4 == 0 && ld >= c && (uintptr_t)p % 16 == 0, PCMI_ERR_INVALID,
+               "%s: needs 16-byte aligned rows, c %% 4 == 0, c <= 1024 (c=%d ld=%lld)", who, c, (long long)ld);
+  return PCMI_OK;
+}
+
+static unsigned stream_grid(int64_t total) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), 256 * 8));
+}
+
+}  // namespace pcmi
+
+using namespace pcmi;
+
+extern "C" {
+
+size_t pcmi_bn_workspace_bytes(int64_t n, int c) {
+  (void)n;
+  return (size_t)kMaxRedBlocks * 2 * c * sizeof(float) + 2 * (size_t)c * sizeof(float) + 512;
+}
+
+int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                      int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean, float* save_invstd,
+                      void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  int rc = check_rows("bn_fwd_train(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_fwd_train(y)", y, y_ld, c);
+  if (rc) return rc;
+  if (residual && (rc = check_rows("bn_fwd_train(residual)", residual, res_ld, c))) return rc;
+  PCMI_REQUIRE(gamma && beta && save_mean && save_invstd && n > 0 && c <= 1024, PCMI_ERR_INVALID, "bn_fwd_train: bad argument");
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_fwd_train: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const RedGeom g = red_geom(n, c);
+  float* part = (float*)ws;
+  colreduce_partial_kernel<0><<<g.nblocks, 256, 0, st>>>(x, x_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, n, g.c4, g.rp,
+                                                        g.rows_per_block, part);
+  PCMI_LAUNCH_CHECK();
+  bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 64)), 64, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
+                                                                       running_mean, running_var, save_mean, save_invstd);
+  PCMI_LAUNCH_CHECK();
+  bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
+                                                        res_ld, relu, y, y_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_bn_fwd_eval(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
+                     const float* running_mean, const float* running_var, float eps, const float* residual,
+                     int64_t res_ld, int relu, float* y, int64_t y_ld, pcmi_stream_t stream) {
+  int rc = check_rows("bn_fwd_eval(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_fwd_eval(y)", y, y_ld, c);
+  if (rc) return rc;
+  PCMI_REQUIRE(gamma && beta && running_mean && running_var, PCMI_ERR_INVALID, "bn_fwd_eval: bad argument");
+  if (n == 0) return PCMI_OK;
+  bn_apply_kernel<<<stream_grid(n * (c / 4)), 256, 0, as_stream(stream)>>>(x, x_ld, n, c / 4, gamma, beta, running_mean,
+                                                                          running_var, eps, 1, residual, res_ld, relu, y, y_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_bn_bwd(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
+                int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                int64_t dx_ld, float* dres, int64_t dres_ld, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                pcmi_stream_t stream) {
+  int rc = check_rows("bn_bwd(dy)", dy, dy_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_bwd(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_bwd(dx)", dx, dx_ld, c);
+  if (rc) return rc;
+  if (relu_mask_y && (rc = check_rows("bn_bwd(y)", relu_mask_y, y_ld, c))) return rc;
+  if (dres && (rc = check_rows("bn_bwd(dres)", dres, dres_ld, c))) return rc;
+  PCMI_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && n > 0, PCMI_ERR_INVALID, "bn_bwd: bad argument");
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const RedGeom g = red_geom(n, c);
+  float* part = (float*)ws;
+  colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
+                                                        g.c4, g.rp, g.rows_per_block, part);
+  PCMI_LAUNCH_CHECK();
+  colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 64)), 64, 0, st>>>(part, g.nblocks, c, dbeta, dgamma);
+  PCMI_LAUNCH_CHECK();
+  bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
+                                                            save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_relu_fwd(const float* x, int64_t x_ld, int64_t n, int c, float* y, int64_t y_ld, pcmi_stream_t stream) {
+  int rc = check_rows("relu_fwd(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("relu_fwd(y)", y, y_ld, c);
+  if (rc) return rc;
+  if (n == 0) return PCMI_OK;
+  eltwise_kernel<0><<<stream_grid(n * (c / 4)), 256, 0, as_stream(stream)>>>(x, x_ld, nullptr, 0, n, c / 4, y, y_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_relu_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, int64_t n, int c, float* dx,
+                  int64_t dx_ld, pcmi_stream_t stream) {
+  int rc = check_rows("relu_bwd(dy)", dy, dy_ld, c);
+  if (rc) return rc;
+  rc = check_rows("relu_bwd(y)", y, y_ld, c);
+  if (rc) return rc;
+  rc = check_rows("relu_bwd(dx)", dx, dx_ld, c);
+  if (rc) return rc;
+  if (n == 0) return PCMI_OK;
+  eltwise_kernel<1><<<stream_grid(n * (c / 4)), 256, 0, as_stream(stream)>>>(dy, dy_ld, y, y_ld, n, c / 4, dx, dx_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_add(const float* a, int64_t a_ld, const float* b, int64_t b_ld, int64_t n, int c, float* y, int64_t y_ld,
+             pcmi_stream_t stream) {
+  int rc = check_rows("add(a)", a, a_ld, c);
+  if (rc) return rc;
+  rc = check_rows("add(b)", b, b_ld, c);
+  if (rc) return rc;
+  rc = check_rows("add(y)", y, y_ld, c);
+  if (rc) return rc;
+  if (n == 0) return PCMI_OK;
+  eltwise_kernel<2><<<stream_grid(n * (c / 4)), 256, 0, as_stream(stream)>>>(a, a_ld, b, b_ld, n, c / 4, y, y_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+static int l2_lanes(int c4) {
+  int l = 1;
+  while (l < c4) l <<= 1;
+  return l;
+}
+
+int pcmi_l2norm_fwd(const float* x, int64_t x_ld, int64_t n, int c, float* y, int64_t y_ld, float* norm,
+                    pcmi_stream_t stream) {
+  int rc = check_rows("l2norm_fwd(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("l2norm_fwd(y)", y, y_ld, c);
+  if (rc) return rc;
+  PCMI_REQUIRE(norm && c <= 256, PCMI_ERR_INVALID, "l2norm_fwd: bad argument (c=%d)", c);
+  if (n == 0) return PCMI_OK;
+  const int lpr = l2_lanes(c / 4);
+  l2norm_kernel<false><<<dim3((unsigned)ceil_div(n, 256 / lpr)), 256, 0, as_stream(stream)>>>(x, x_ld, nullptr, 0, norm, n, c / 4,
+                                                                                           lpr, y, y_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_l2norm_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld, const float* norm, int64_t n, int c,
+                    float* dx, int64_t dx_ld, pcmi_stream_t stream) {
+  int rc = check_rows("l2norm_bwd(dy)", dy, dy_ld, c);
+  if (rc) return rc;
+  rc = check_rows("l2norm_bwd(y)", y, y_ld, c);
+  if (rc) return rc;
+  rc = check_rows("l2norm_bwd(dx)", dx, dx_ld, c);
+  if (rc) return rc;
+  PCMI_REQUIRE(norm && c <= 256, PCMI_ERR_INVALID, "l2norm_bwd: bad argument (c=%d)", c);
+  if (n == 0) return PCMI_OK;
+  const int lpr = l2_lanes(c / 4);
+  l2norm_kernel<true><<<dim3((unsigned)ceil_div(n, 256 / lpr)), 256, 0, as_stream(stream)>>>(
+      dy, dy_ld, y, y_ld, const_cast<float*>(norm), n, c / 4, lpr, dx, dx_ld);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+}  // extern "C"

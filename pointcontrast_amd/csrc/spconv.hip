@@ -1,0 +1,570 @@
+// Sparse convolution forward / backward-data on the fp32 matrix cores of gfx950.
+//
+// Formulation (output-stationary implicit GEMM -- no float atomics, deterministic):
+//     out[r, :] = sum_k  X[ idx_k(r), : ] @ B_k          r = a tile of output rows
+// where idx_k(r) comes from the neighbour table (map.nbr) or, for the one-offset-per-row
+// direction of a stride-2 map, from the per-offset pair lists.  The same kernel serves
+//   * 3^3 conv fwd            idx = nbr[k][r],          B_k = W[k]
+//   * 3^3 conv bwd-data       idx = nbr[k][r],          B_k = W[mirror(k)]^T
+//   * 2^3/s2 conv fwd         idx = child[k][r],        B_k = W[k]          (rows = coarse)
+//   * 2^3/s2 conv-tr bwd-data idx = child[k][r],        B_k = W[k]^T        (rows = coarse)
+//   * 2^3/s2 conv-tr fwd      pair mode, one k per tile, B = W[k]           (rows = fine)
+//   * 2^3/s2 conv bwd-data    pair mode, one k per tile, B = W[k]^T         (rows = fine)
+//   * 1x1 conv fwd / bwd-data idx = r,                  B = W or W^T
+//
+// Tiling (wave = 64, workgroup = 4 waves):
+//   v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][kk = l>>5] and B[kk = l>>5][j = l&31].
+//   A (gathered feature rows) goes STRAIGHT from global memory to the A operand: lane (i, h)
+//   loads the float4 X[idx(i)][c0 + 8*blk + 4*h .. +3]; its four floats are the A values of
+//   four consecutive MFMA steps, i.e. MFMA step s of block blk contracts over the physical
+//   channel  c(s, h) = c0 + 8*blk + 4*h + s  -- any bijection works as long as B uses the same
+//   one.  A half-wave therefore reads 32 rows x 16 B and both halves together cover 32 B
+//   contiguous per row; successive blocks walk along the same 128-byte line.  No LDS round
+//   trip, no barrier for A, absent neighbours are just zeros in the register.
+//   B (weights, shared by every row of the tile) is staged through LDS in [32 x NS] chunks,
+//   double buffered, one __syncthreads per chunk.
+//   RW = number of 32-row groups per workgroup; the remaining 4/RW wave groups split the
+//   eight-channel blocks of each chunk (intra-workgroup split of the contraction) and are
+//   summed through LDS at the end.  RW=4: 128-row tiles for the big levels; RW=1: 32-row
+//   tiles (+ optional split of the offset range over blockIdx.z into a partial buffer) so
+//   that the small, wide levels still fill 256 CUs.
+#include <algorithm>
+
+#include "common.h"
+
+namespace pcmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kKC = 32;  // contraction channels per staged weight chunk
+
+struct ConvArgs {
+  const float* x;        // gathered operand [*, x_ld]
+  int64_t x_ld;
+  int C;                 // contraction size (multiple of 32)
+  const float* w;        // weights [K][cin][cout] in memory
+  int64_t w_kstride;     // floats per weight slice (cin*cout)
+  int64_t w_sc, w_sn;    // B_k[c][n] = w[wk*w_kstride + c*w_sc + n*w_sn]
+  int N;                 // output channels (multiple of 32)
+  const int32_t* nbr;    // [K][n_rows] or nullptr (identity)
+  const int32_t* pair_src;  // pair mode: gather row per pair
+  const int32_t* pair_dst;  // pair mode: output row per pair
+  const int64_t* offs;   // pair mode: [K+1] device group offsets
+  int K;                 // number of offsets
+  int32_t wsel[PCMI_MAX_KERNEL_VOLUME];  // weight slice used by offset k
+  int64_t n_rows;        // output rows
+  float* out;            // [n_rows, out_ld]  (or partial buffer when ksplit > 1)
+  int64_t out_ld;
+  int64_t split_stride;  // floats between partial buffers
+  int ksplit;            // offsets are divided into ksplit contiguous ranges over blockIdx.z
+  const float* bias;     // nullable, only when ksplit == 1
+};
+
+template <int NT, int RW, bool WT, bool PAIR>
+__global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
+  constexpr int TM = 32 * RW;        // rows per workgroup tile
+  constexpr int KG = 4 / RW;         // wave groups splitting the contraction blocks
+  constexpr int BPG = 4 / KG;        // eight-channel blocks per wave group per chunk
+  constexpr int NS = 32 * NT;        // output-channel slice of this workgroup
+  constexpr int LDB = WT ? NS + 1 : NS;
+  constexpr int KSLOTS = PAIR ? 1 : PCMI_MAX_KERNEL_VOLUME;
+  constexpr int STAGE_FLOATS = 2 * kKC * LDB;
+  constexpr int RED_FLOATS = (KG > 1) ? (KG - 1) * RW * 32 * NS : 0;
+  constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
+
+  __shared__ __attribute__((aligned(16))) float s_f[LDS_FLOATS];
+  __shared__ int32_t s_idx[KSLOTS][TM];
+  __shared__ int32_t s_orow[TM];
+  __shared__ int32_t s_klist[KSLOTS];
+  __shared__ int32_t s_nk;
+  __shared__ int64_t s_tile[2];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int rg = wave % RW, kg = wave / RW;
+  const int n0 = blockIdx.y * NS;
+
+  // ---- tile descriptor -------------------------------------------------------------------
+  int k_single = 0;
+  if (PAIR) {
+    if (t == 0) {
+      int64_t tile = blockIdx.x, found_k = -1, p0 = 0;
+      for (int k = 0; k < a.K; ++k) {
+        const int64_t len = a.offs[k + 1] - a.offs[k];
+        const int64_t nt = (len + TM - 1) / TM;
+        if (tile < nt) {
+          found_k = k;
+          p0 = a.offs[k] + tile * TM;
+          break;
+        }
+        tile -= nt;
+      }
+      s_tile[0] = found_k;
+      s_tile[1] = p0;
+    }
+    __syncthreads();
+    if (s_tile[0] < 0) return;
+    k_single = (int)s_tile[0];
+    const int64_t p0 = s_tile[1], pend = a.offs[k_single + 1];
+    if (t < TM) {
+      const int64_t p = p0 + t;
+      s_idx[0][t] = p < pend ? a.pair_src[p] : -1;
+      s_orow[t] = p < pend ? a.pair_dst[p] : -1;
+    }
+    if (t == 0) {
+      s_klist[0] = k_single;
+      s_nk = 1;
+    }
+  } else {
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
+    const int kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
+    const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (int32_t)(row0 + t) : -1;
+    for (int p = t; p < (kend - kbeg) * TM; p += 256) {
+      const int kk = p / TM, rr = p - kk * TM;
+      const int64_t row = row0 + rr;
+      int32_t v = -1;
+      if (row < a.n_rows) v = a.nbr ? a.nbr[(int64_t)(kbeg + kk) * a.n_rows + row] : (int32_t)row;
+      s_idx[kk][rr] = v;
+    }
+    __syncthreads();
+    // compact list of offsets that have at least one neighbour in this tile
+    if (t < 64) {
+      int nk = 0;
+      for (int kk = 0; kk < kend - kbeg; ++kk) {
+        bool any = false;
+        for (int rr = t; rr < TM; rr += 64) any |= (s_idx[kk][rr] >= 0);
+        if (__any(any)) {
+          if (t == 0) s_klist[nk] = kk;
+          ++nk;
+        }
+      }
+      if (t == 0) s_nk = nk;
+    }
+  }
+  __syncthreads();
+  const int nk = s_nk;
+  const int nch = a.C / kKC;
+  const int nsteps = nk * nch;
+  const int kbeg_blk = PAIR ? 0 : (int)((int64_t)a.K * blockIdx.z / a.ksplit);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  // ---- staging helpers -------------------------------------------------------------------
+  constexpr int NB4 = (kKC * NS / 4 + 255) / 256;  // float4 loads per thread per chunk
+  float4 breg[NB4];
+  auto load_b = [&](int step) {
+    const int kslot = s_klist[step / nch];
+    const int c0 = (step % nch) * kKC;
+    const int wk = PAIR ? a.wsel[k_single] : a.wsel[kbeg_blk + kslot];
+    const float* wb = a.w + (int64_t)wk * a.w_kstride;
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int e = t + i * 256;  // float4 index inside the chunk
+      if (kKC * NS / 4 % 256 == 0 || e < kKC * NS / 4) {
+        if (!WT) {
+          const int c = e / (NS / 4), n4 = e % (NS / 4);
+          breg[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(c0 + c) * a.w_sc + n0 + n4 * 4);
+        } else {
+          const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+          breg[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(n0 + n) * a.w_sn + c0 + c4 * 4);
+        }
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+    float* sb = s_f + buf * (kKC * LDB);
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int e = t + i * 256;
+      if (kKC * NS / 4 % 256 == 0 || e < kKC * NS / 4) {
+        if (!WT) {
+          const int c = e / (NS / 4), n4 = e % (NS / 4);
+          *reinterpret_cast<float4*>(sb + c * LDB + n4 * 4) = breg[i];
+        } else {
+          const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+          sb[(c4 * 4 + 0) * LDB + n] = breg[i].x;
+          sb[(c4 * 4 + 1) * LDB + n] = breg[i].y;
+          sb[(c4 * 4 + 2) * LDB + n] = breg[i].z;
+          sb[(c4 * 4 + 3) * LDB + n] = breg[i].w;
+        }
+      }
+    }
+  };
+  float4 acur[BPG], anext[BPG];
+  bool vcur = false, vnext = false;
+  auto load_a = [&](int step, float4* dst) -> bool {
+    const int kslot = s_klist[step / nch];
+    const int c0 = (step % nch) * kKC;
+    const int32_t idx = s_idx[kslot][rg * 32 + r];
+    if (idx >= 0) {
+      const float* xp = a.x + (int64_t)idx * a.x_ld + c0 + 4 * h;
+#pragma unroll
+      for (int b = 0; b < BPG; ++b)
+        dst[b] = *reinterpret_cast<const float4*>(xp + 8 * (kg * BPG + b));
+    } else {
+#pragma unroll
+      for (int b = 0; b < BPG; ++b) dst[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return __any(idx >= 0);
+  };
+
+  // ---- main loop --------------------------------------------------------------------------
+  if (nsteps > 0) {
+    load_b(0);
+    vcur = load_a(0, acur);
+    store_b(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      const bool more = step + 1 < nsteps;
+      if (more) {
+        load_b(step + 1);
+        vnext = load_a(step + 1, anext);
+      }
+      if (vcur) {
+        const float* sb = s_f + (step & 1) * (kKC * LDB) + r;
+#pragma unroll
+        for (int b = 0; b < BPG; ++b) {
+          const float av[4] = {acur[b].x, acur[b].y, acur[b].z, acur[b].w};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float* brow = sb + (8 * (kg * BPG + b) + 4 * h + s) * LDB;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], brow[nt * 32], acc[nt], 0, 0, 0);
+          }
+        }
+      }
+      if (more) store_b((step + 1) & 1);
+      __syncthreads();
+      if (more) {
+#pragma unroll
+        for (int b = 0; b < BPG; ++b) acur[b] = anext[b];
+        vcur = vnext;
+      }
+    }
+  }
+
+  // ---- reduce the contraction split across wave groups ----------------------------------------
+  if (KG > 1) {
+    // (the main loop ends with a barrier, so the staging area is free)
+    if (kg > 0) {
+      float* red = s_f + ((kg - 1) * RW + rg) * 32 * NS;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int i = (j & 3) + 8 * (j >> 2) + 4 * h;
+          red[i * NS + nt * 32 + r] = acc[nt][j];
+        }
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float* red = s_f + ((g - 1) * RW + rg) * 32 * NS;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int i = (j & 3) + 8 * (j >> 2) + 4 * h;
+            acc[nt][j] += red[i * NS + nt * 32 + r];
+          }
+      }
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  if (kg == 0) {
+    float* outp = a.out + (PAIR ? 0 : (int64_t)blockIdx.z * a.split_stride);
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = a.bias ? a.bias[n0 + nt * 32 + r] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int i = (j & 3) + 8 * (j >> 2) + 4 * h;
+      const int32_t orow = s_orow[rg * 32 + i];
+      if (orow >= 0) {
+        float* op = outp + (int64_t)orow * a.out_ld + n0 + r;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[nt][j] + bv[nt];
+      }
+    }
+  }
+}
+
+// out[row, n] = sum_s partial[s][row, n] (+ bias)
+__global__ void split_reduce_kernel(const float* __restrict__ part, int64_t split_stride, int ksplit,
+                                    int64_t n_rows, int N, const float* __restrict__ bias,
+                                    float* __restrict__ out, int64_t out_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  const int n4 = N / 4;
+  if (idx >= n_rows * n4) return;
+  const int64_t row = idx / n4;
+  const int c = (int)(idx % n4) * 4;
+  float4 s = *reinterpret_cast<const float4*>(part + row * N + c);
+  for (int i = 1; i < ksplit; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(part + i * split_stride + row * N + c);
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  if (bias) {
+    s.x += bias[c];
+    s.y += bias[c + 1];
+    s.z += bias[c + 2];
+    s.w += bias[c + 3];
+  }
+  *reinterpret_cast<float4*>(out + row * out_ld + c) = s;
+}
+
+// ---- tiny-channel stem (cin < 8: conv0p1s1 has cin = 3): plain VALU, HBM-bound -----------------
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                       const float* __restrict__ w, int cout,
+                                                       const int32_t* __restrict__ nbr, int K,
+                                                       int64_t n_rows, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int64_t out_ld) {
+  extern __shared__ float s_w[];  // [K][CIN][cout]
+  for (int i = threadIdx.x; i < K * CIN * cout; i += 256) s_w[i] = w[i];
+  __syncthreads();
+  const int rows_per_block = 256 / 32;
+  const int n = threadIdx.x & 31;
+  const int64_t row = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 5);
+  if (row >= n_rows) return;
+  for (int nn = n; nn < cout; nn += 32) {
+    float acc = bias ? bias[nn] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int32_t idx = nbr ? nbr[(int64_t)k * n_rows + row] : (int32_t)row;
+      if (idx < 0) continue;
+      const float* xp = x + (int64_t)idx * x_ld;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) acc = fmaf(xp[c], s_w[(k * CIN + c) * cout + nn], acc);
+    }
+    out[row * out_ld + nn] = acc;
+  }
+}
+
+template <int NT, int RW, bool WT, bool PAIR>
+static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  spconv_mfma_kernel<NT, RW, WT, PAIR><<<grid, 256, 0, st>>>(a);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+template <int RW, bool WT, bool PAIR>
+static int launch_nt(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  switch (NT) {
+    case 1: return launch_one<1, RW, WT, PAIR>(a, grid, st);
+    case 2: return launch_one<2, RW, WT, PAIR>(a, grid, st);
+    case 3: return launch_one<3, RW, WT, PAIR>(a, grid, st);
+    case 4: return launch_one<4, RW, WT, PAIR>(a, grid, st);
+  }
+  set_error("spconv: bad NT %d", NT);
+  return PCMI_ERR_INVALID;
+}
+
+template <bool WT, bool PAIR>
+static int launch_rw(int RW, int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  switch (RW) {
+    case 4: return launch_nt<4, WT, PAIR>(NT, a, grid, st);
+    case 2: return launch_nt<2, WT, PAIR>(NT, a, grid, st);
+    case 1: return launch_nt<1, WT, PAIR>(NT, a, grid, st);
+  }
+  set_error("spconv: bad RW %d", RW);
+  return PCMI_ERR_INVALID;
+}
+
+struct Plan {
+  int RW, NT, ksplit;
+};
+constexpr int kMaxKSplit = 9;
+
+static int g_num_cu = 0;
+static int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cu = prop.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+// rows: output rows (or pairs in pair mode); N: output channels; K: offsets
+static Plan make_plan(int64_t rows, int N, int K, bool pair) {
+  Plan p;
+  const int nt_all = N / 32;
+  p.NT = nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
+  p.ksplit = 1;
+  if (rows >= 32768)
+    p.RW = 4;
+  else if (rows >= 8192)
+    p.RW = 2;
+  else
+    p.RW = 1;
+  if (p.RW == 1) {
+    // small levels: narrower slices and a split of the offset range until the chip is full
+    if (p.NT > 2) p.NT = (nt_all % 2 == 0) ? 2 : 1;
+    const int64_t wgs = ceil_div(rows, 32) * (nt_all / p.NT);
+    const int64_t target = 2 * num_cu();
+    if (!pair && K > 1 && wgs < target)
+      p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
+  }
+  return p;
+}
+
+static size_t partial_bytes(int64_t rows, int N, int K) {
+  // upper bound of make_plan's ksplit partial buffers, only for the RW == 1 regime
+  if (rows >= 8192 || K <= 1) return 0;
+  return (size_t)std::min(K, kMaxKSplit) * rows * N * sizeof(float);
+}
+
+// One gathered GEMM:  out[rows, N] = sum_k x[idx_k(rows)] @ B_k
+static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int cin, int cout,
+                        bool w_transposed, int N, const pcmi_kmap_t* map, bool pair_mode,
+                        bool swap_pairs, const int32_t* wsel, const float* bias, float* out,
+                        int64_t out_ld, int64_t n_rows, void* ws, size_t ws_bytes, hipStream_t st) {
+  PCMI_REQUIRE(C % 32 == 0 && N % 32 == 0, PCMI_ERR_UNSUPPORTED,
+               "spconv: channels (%d -> %d) must be multiples of 32 on the MFMA path", C, N);
+  PCMI_REQUIRE(x_ld % 4 == 0 && out_ld >= N && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0),
+               PCMI_ERR_INVALID, "spconv: operands must be 16-byte aligned with ld %% 4 == 0");
+  if (n_rows == 0) return PCMI_OK;
+  ConvArgs a;
+  a.x = x;
+  a.x_ld = x_ld;
+  a.C = C;
+  a.w = w;
+  a.w_kstride = (int64_t)cin * cout;
+  if (!w_transposed) {  // B[c][n] = W[c][n], contraction over cin
+    a.w_sc = cout;
+    a.w_sn = 1;
+  } else {  // B[c][n] = W[n][c], contraction over cout
+    a.w_sc = 1;
+    a.w_sn = cout;
+  }
+  a.N = N;
+  a.K = map ? map->K : 1;
+  for (int k = 0; k < PCMI_MAX_KERNEL_VOLUME; ++k) a.wsel[k] = wsel ? wsel[k] : k;
+  a.n_rows = n_rows;
+  a.bias = bias;
+  a.nbr = nullptr;
+  a.pair_src = a.pair_dst = nullptr;
+  a.offs = nullptr;
+  a.ksplit = 1;
+  a.split_stride = 0;
+  a.out = out;
+  a.out_ld = out_ld;
+  if (pair_mode) {
+    a.pair_src = swap_pairs ? map->pair_in : map->pair_out;
+    a.pair_dst = swap_pairs ? map->pair_out : map->pair_in;
+    a.offs = map->offs;
+    Plan p = make_plan(n_rows, N, a.K, true);
+    const int TM = 32 * p.RW;
+    int64_t tiles = 0;
+    for (int k = 0; k < a.K; ++k) tiles += ceil_div(map->offs_host[k + 1] - map->offs_host[k], TM);
+    if (tiles == 0) return PCMI_OK;
+    dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), 1);
+    return w_transposed ? launch_rw<true, true>(p.RW, p.NT, a, grid, st)
+                        : launch_rw<false, true>(p.RW, p.NT, a, grid, st);
+  }
+  a.nbr = map ? map->nbr : nullptr;
+  Plan p = make_plan(n_rows, N, a.K, false);
+  if (p.ksplit > 1) {
+    const size_t need = (size_t)p.ksplit * n_rows * N * sizeof(float);
+    PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
+    a.ksplit = p.ksplit;
+    a.split_stride = n_rows * N;
+    a.out = (float*)ws;
+    a.out_ld = N;
+    a.bias = nullptr;
+  }
+  dim3 grid((unsigned)ceil_div(n_rows, 32 * p.RW), (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
+  int rc = w_transposed ? launch_rw<true, false>(p.RW, p.NT, a, grid, st)
+                        : launch_rw<false, false>(p.RW, p.NT, a, grid, st);
+  if (rc) return rc;
+  if (p.ksplit > 1) {
+    const int64_t n4 = n_rows * (N / 4);
+    split_reduce_kernel<<<dim3((unsigned)ceil_div(n4, 256)), 256, 0, st>>>((const float*)ws, a.split_stride, p.ksplit,
+                                                                         n_rows, N, bias, out, out_ld);
+    PCMI_LAUNCH_CHECK();
+  }
+  return PCMI_OK;
+}
+
+size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K) {
+  return std::max(partial_bytes(n_out, cout, K), partial_bytes(n_in, cin, K));
+}
+
+}  // namespace pcmi
+
+using namespace pcmi;
+
+extern "C" {
+
+int pcmi_spconv_fwd(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
+                    const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
+                    int64_t n_out, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  PCMI_REQUIRE(in && weight && out && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_fwd: null/empty argument");
+  hipStream_t st = as_stream(stream);
+  if (map) {
+    const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
+    PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_fwd: rows (%lld -> %lld) do not match the map (%lld -> %lld)",
+                 (long long)n_in, (long long)n_out, (long long)mi, (long long)mo);
+  } else {
+    PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_fwd: dense path needs n_in == n_out");
+  }
+  if (cin < 8) {
+    PCMI_REQUIRE(cin == 3 && !transpose && (!map || map->stride == 1), PCMI_ERR_UNSUPPORTED,
+                 "spconv_fwd: cin=%d only supported as the 3-channel stride-1 stem", cin);
+    if (n_out == 0) return PCMI_OK;
+    const int K = map ? map->K : 1;
+    const size_t lds = sizeof(float) * K * 3 * cout;
+    stem_fwd_kernel<3><<<dim3((unsigned)ceil_div(n_out, 8)), 256, lds, st>>>(in, in_ld, weight, cout, map ? map->nbr : nullptr,
+                                                                            K, n_out, bias, out, out_ld);
+    PCMI_LAUNCH_CHECK();
+    return PCMI_OK;
+  }
+  // rows = output rows.  transposed conv over a stride-2 map: one offset per fine row -> pair mode
+  const bool pair_mode = map && transpose;
+  PCMI_REQUIRE(!(map && transpose && map->stride != 2), PCMI_ERR_UNSUPPORTED, "spconv_fwd: transposed conv needs a stride-2 map");
+  return run_gathered(in, in_ld, cin, weight, cin, cout, false, cout, map, pair_mode, false, nullptr, bias, out,
+                      out_ld, n_out, ws, ws_bytes, st);
+}
+
+int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
+                         const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
+                         void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  PCMI_REQUIRE(gout && weight && gin && cin >= 8 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_data: bad argument (cin=%d)", cin);
+  hipStream_t st = as_stream(stream);
+  if (!map) {
+    PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_data: dense path needs n_in == n_out");
+    return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, nullptr, false, false, nullptr, nullptr,
+                        gin, gin_ld, n_in, ws, ws_bytes, st);
+  }
+  const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
+  PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_bwd_data: rows do not match the map");
+  if (map->stride == 1) {
+    // gin[i] = sum_k gout[nbr[k][i]] @ W[mirror(k)]^T  (in and out rows coincide)
+    PCMI_REQUIRE(!transpose, PCMI_ERR_UNSUPPORTED, "spconv_bwd_data: transposed stride-1 conv is not on the hot path");
+    return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, false, false, map->mirror, nullptr,
+                        gin, gin_ld, n_in, ws, ws_bytes, st);
+  }
+  if (!transpose) {
+    // strided conv: every fine (input) row has exactly one (coarse row, k): pair mode, rows = fine
+    return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, true, false, nullptr, nullptr, gin,
+                        gin_ld, n_in, ws, ws_bytes, st);
+  }
+  // transposed conv: gin (coarse) gathers its children: nbr table, rows = coarse
+  return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, false, false, nullptr, nullptr, gin,
+                      gin_ld, n_in, ws, ws_bytes, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,414 @@
+// Sparse convolution backward-weight on the fp32 matrix cores:
+//     gW[k][c][n] = sum over the pairs p of offset k of  X[i_p][c] * G[j_p][n]
+// i.e. per offset a [cin x M_k] @ [M_k x cout] GEMM whose contraction runs over the pairs.
+//
+// v_mfma_f32_32x32x2_f32 contracts two pairs per instruction: lane l = (i = l&31, h = l>>5)
+// supplies A[i][h] = X[row_in(p+h)][c(i)] and B[h][j=i] = G[row_out(p+h)][n(j)].  Both operands
+// are read STRAIGHT from global memory, fully coalesced: a half-wave reads CT (resp. NT)
+// consecutive floats per lane from ONE feature row, so 32 lanes x CT x 4 B is one contiguous
+// run of the row; the CT floats of a lane feed CT different 32x32 output tiles (tile t covers
+// the channels c0 + CT*i + t), so one vector load per operand feeds CT*NT MFMAs.  No LDS in
+// the main loop.  The 4 waves of a workgroup take interleaved 64-pair groups of the chunk, are
+// summed through LDS, and the workgroup writes one [32*CT x 32*NT] slab; a second kernel sums
+// the slabs of each offset in fixed order (deterministic, no float atomics).
+#include <algorithm>
+
+#include "common.h"
+
+namespace pcmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+  const float* x;   // [*, x_ld]  rows indexed by src_x
+  int64_t x_ld;
+  const float* g;   // [*, g_ld]  rows indexed by src_g
+  int64_t g_ld;
+  const int32_t* idx_x;  // [M] or nullptr (identity)
+  const int32_t* idx_g;  // [M] or nullptr (identity)
+  const int64_t* offs;   // [K+1] device (nullptr: single group [0, M))
+  int64_t M;
+  int K;
+  int cin, cout;
+  int chunk;        // pairs per workgroup (multiple of 256)
+  float* slabs;     // [n_chunks][cin][cout]
+};
+
+template <int V>
+struct VecLoad;
+template <>
+struct VecLoad<1> {
+  static __device__ inline void ld(const float* p, float* v) { v[0] = *p; }
+};
+template <>
+struct VecLoad<2> {
+  static __device__ inline void ld(const float* p, float* v) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x;
+    v[1] = t.y;
+  }
+};
+template <>
+struct VecLoad<3> {
+  static __device__ inline void ld(const float* p, float* v) {
+    v[0] = p[0];
+    v[1] = p[1];
+    v[2] = p[2];
+  }
+};
+template <>
+struct VecLoad<4> {
+  static __device__ inline void ld(const float* p, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x;
+    v[1] = t.y;
+    v[2] = t.z;
+    v[3] = t.w;
+  }
+};
+
+// chunk c of the launch -> (offset k, first pair, last pair)
+__device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int chunk, int64_t c,
+                                    int* k_out, int64_t* pb, int64_t* pe) {
+  if (!offs) {
+    *k_out = 0;
+    *pb = c * chunk;
+    *pe = min(*pb + (int64_t)chunk, M);
+    return;
+  }
+  for (int k = 0; k < K; ++k) {
+    const int64_t b = offs[k], e = offs[k + 1];
+    const int64_t nc = (e - b + chunk - 1) / chunk;
+    if (c < nc) {
+      *k_out = k;
+      *pb = b + c * chunk;
+      *pe = min(*pb + (int64_t)chunk, e);
+      return;
+    }
+    c -= nc;
+  }
+  *k_out = -1;
+  *pb = *pe = 0;
+}
+
+template <int CT, int NT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
+  __shared__ float s_red[32 * CT][32 * NT + 1];
+  __shared__ int64_t s_desc[3];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int c0 = blockIdx.y * 32 * CT, n0 = blockIdx.z * 32 * NT;
+  if (t == 0) {
+    int k;
+    int64_t pb, pe;
+    locate_chunk(a.offs, a.K, a.M, a.chunk, blockIdx.x, &k, &pb, &pe);
+    s_desc[0] = k;
+    s_desc[1] = pb;
+    s_desc[2] = pe;
+  }
+  __syncthreads();
+  if (s_desc[0] < 0) return;
+  const int64_t pb = s_desc[1], pe = s_desc[2];
+
+  f32x16 acc[CT][NT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[ct][nt][j] = 0.f;
+
+  const float* xcol = a.x + c0 + CT * i;
+  const float* gcol = a.g + n0 + NT * i;
+  // each wave walks 64-pair groups: group index = wave, wave+4, ...
+  for (int64_t g0 = pb + (int64_t)wave * 64; g0 < pe; g0 += 256) {
+    const int64_t p = g0 + lane;
+    int32_t rx = -1, rg = -1;
+    if (p < pe) {
+      rx = a.idx_x ? a.idx_x[p] : (int32_t)p;
+      rg = a.idx_g ? a.idx_g[p] : (int32_t)p;
+    }
+    const int npairs = (int)min((int64_t)64, pe - g0);
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+      if (2 * s >= npairs) break;
+      const int32_t ix = __shfl(rx, 2 * s + h, 64);
+      const int32_t ig = __shfl(rg, 2 * s + h, 64);
+      float av[CT], bv[NT];
+      if (ix >= 0) {
+        VecLoad<CT>::ld(xcol + (int64_t)ix * a.x_ld, av);
+        VecLoad<NT>::ld(gcol + (int64_t)ig * a.g_ld, bv);
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) av[ct] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = 0.f;
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[nt], acc[ct][nt], 0, 0, 0);
+    }
+  }
+
+  // reduce the 4 waves one after the other through ONE LDS tile, wave 0 writes the slab
+  for (int src = 1; src < 4; ++src) {
+    if (wave == src) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            s_red[ct * 32 + row][nt * 32 + i] = acc[ct][nt][j];
+          }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            acc[ct][nt][j] += s_red[ct * 32 + row][nt * 32 + i];
+          }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.cin * a.cout;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          // tile (ct, nt): row = lane index of the A role (cin), col = lane index i of the B role (cout)
+          const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+          const int c = c0 + CT * row + ct, n = n0 + NT * i + nt;
+          slab[(int64_t)c * a.cout + n] = acc[ct][nt][j];
+        }
+  }
+}
+
+// gW[k][e] = sum over the chunks of offset k of slab[chunk][e]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, const int64_t* __restrict__ offs,
+                                    int K, int64_t M, int chunk, int64_t per_k /* cin*cout */,
+                                    float* __restrict__ gw) {
+  const int k = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per_k) return;
+  int64_t first = 0, count;
+  if (!offs) {
+    count = (M + chunk - 1) / chunk;
+  } else {
+    for (int kk = 0; kk < k; ++kk) first += (offs[kk + 1] - offs[kk] + chunk - 1) / chunk;
+    count = (offs[k + 1] - offs[k] + chunk - 1) / chunk;
+  }
+  float s = 0.f;
+  for (int64_t c = 0; c < count; ++c) s += slabs[(first + c) * per_k + e];
+  gw[(int64_t)k * per_k + e] = s;
+}
+
+// tiny-channel stem (cin = 3): slab[chunk][c][n] = sum_p x[i_p][c] * g[j_p][n]
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(WgradArgs a) {
+  __shared__ float s_part[8][CIN][33];
+  __shared__ int64_t s_desc[3];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    int k;
+    int64_t pb, pe;
+    locate_chunk(a.offs, a.K, a.M, a.chunk, blockIdx.x, &k, &pb, &pe);
+    s_desc[0] = k;
+    s_desc[1] = pb;
+    s_desc[2] = pe;
+  }
+  __syncthreads();
+  if (s_desc[0] < 0) return;
+  const int64_t pb = s_desc[1], pe = s_desc[2];
+  const int n = t & 31, sub = t >> 5;
+  float* slab = a.slabs + (int64_t)blockIdx.x * a.cin * a.cout;
+  for (int nb = 0; nb < a.cout; nb += 32) {
+    float acc[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+    for (int64_t p = pb + sub; p < pe; p += 8) {
+      const int32_t ix = a.idx_x ? a.idx_x[p] : (int32_t)p;
+      const int32_t ig = a.idx_g ? a.idx_g[p] : (int32_t)p;
+      const float gv = a.g[(int64_t)ig * a.g_ld + nb + n];
+      const float* xp = a.x + (int64_t)ix * a.x_ld;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) acc[c] = fmaf(xp[c], gv, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) s_part[sub][c][n] = acc[c];
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += s_part[q][c][n];
+        slab[(int64_t)c * a.cout + nb + n] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// column sums (bias gradient): two-level, deterministic
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, int64_t g_ld,
+                                                             int64_t n, int c, int rows_per_block,
+                                                             float* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(r0 + rows_per_block, n);
+  for (int col = threadIdx.x; col < c; col += 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += g[r * g_ld + col];
+    part[(int64_t)blockIdx.x * c + col] = s;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblocks, int c,
+                                    float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= c) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * c + col];
+  out[col] = s;
+}
+
+template <int CT>
+static int launch_wg_nt(int NT, const WgradArgs& a, dim3 grid, hipStream_t st) {
+  switch (NT) {
+    case 1: wgrad_mfma_kernel<CT, 1><<<grid, 256, 0, st>>>(a); break;
+    case 2: wgrad_mfma_kernel<CT, 2><<<grid, 256, 0, st>>>(a); break;
+    case 3: wgrad_mfma_kernel<CT, 3><<<grid, 256, 0, st>>>(a); break;
+    default: set_error("wgrad: bad NT %d", NT); return PCMI_ERR_INVALID;
+  }
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+static int tiles_per_wg(int tiles32) {  // tiles (of 32 channels) a workgroup covers per axis
+  if (tiles32 % 3 == 0) return 3;
+  if (tiles32 % 2 == 0) return 2;
+  return 1;
+}
+
+static int wgrad_chunk(int64_t M, int K) {
+  // aim at ~3 workgroups per CU worth of chunks over all offsets
+  int64_t c = ceil_div(M, 768);
+  c = std::max<int64_t>(256, std::min<int64_t>(4096, align_up((size_t)c, 256)));
+  (void)K;
+  return (int)c;
+}
+
+static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk) {
+  if (!map) return ceil_div(M, chunk);
+  int64_t n = 0;
+  for (int k = 0; k < map->K; ++k) n += ceil_div(map->offs_host[k + 1] - map->offs_host[k], chunk);
+  return n;
+}
+
+size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M) {
+  if (M <= 0) M = std::max(n_in, n_out);
+  const int chunk = wgrad_chunk(M, K);
+  const int64_t nchunks = ceil_div(M, chunk) + K;
+  return (size_t)nchunks * cin * cout * sizeof(float) + (size_t)1024 * cout * sizeof(float);
+}
+
+}  // namespace pcmi
+
+using namespace pcmi;
+
+namespace pcmi {
+size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K);
+}
+
+extern "C" {
+
+size_t pcmi_spconv_workspace_bytes(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M) {
+  return std::max(spconv_fwd_bwd_workspace(n_in, n_out, cin, cout, K),
+                  spconv_wgrad_workspace(n_in, n_out, cin, cout, K, M)) + 256;
+}
+
+int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                           int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
+                           float* gweight, float* gbias, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  PCMI_REQUIRE(in && gout && gweight && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_weight: bad argument");
+  hipStream_t st = as_stream(stream);
+  const int K = map ? map->K : 1;
+  int64_t M;
+  if (map) {
+    const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
+    PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: rows do not match the map");
+    M = map->M;
+  } else {
+    PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: dense path needs n_in == n_out");
+    M = n_in;
+  }
+  const int64_t per_k = (int64_t)cin * cout;
+  if (M == 0) {
+    PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
+    if (gbias) PCMI_HIP_CHECK(hipMemsetAsync(gbias, 0, sizeof(float) * cout, st));
+    return PCMI_OK;
+  }
+  WgradArgs a;
+  a.x = in;
+  a.x_ld = in_ld;
+  a.g = gout;
+  a.g_ld = gout_ld;
+  a.idx_x = map ? (transpose ? map->pair_out : map->pair_in) : nullptr;
+  a.idx_g = map ? (transpose ? map->pair_in : map->pair_out) : nullptr;
+  a.offs = map ? map->offs : nullptr;
+  a.M = M;
+  a.K = K;
+  a.cin = cin;
+  a.cout = cout;
+  a.chunk = wgrad_chunk(M, K);
+  const int64_t nchunks = wgrad_num_chunks(map, M, a.chunk);
+  const size_t slab_bytes = (size_t)nchunks * per_k * sizeof(float);
+  const size_t bias_bytes = gbias ? (size_t)1024 * cout * sizeof(float) : 0;
+  PCMI_REQUIRE(ws && ws_bytes >= slab_bytes + bias_bytes, PCMI_ERR_WORKSPACE,
+               "spconv_bwd_weight: workspace %zu < %zu bytes", ws_bytes, slab_bytes + bias_bytes);
+  a.slabs = (float*)ws;
+  if (cin < 8) {
+    PCMI_REQUIRE(cin == 3 && cout % 32 == 0, PCMI_ERR_UNSUPPORTED, "spconv_bwd_weight: cin=%d only supported as the 3-channel stem", cin);
+    stem_wgrad_kernel<3><<<dim3((unsigned)nchunks), 256, 0, st>>>(a);
+    PCMI_LAUNCH_CHECK();
+  } else {
+    PCMI_REQUIRE(cin % 32 == 0 && cout % 32 == 0, PCMI_ERR_UNSUPPORTED,
+                 "spconv_bwd_weight: channels (%d, %d) must be multiples of 32", cin, cout);
+    PCMI_REQUIRE(in_ld % 4 == 0 && gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0,
+                 PCMI_ERR_INVALID, "spconv_bwd_weight: operands must be 16-byte aligned with ld %% 4 == 0");
+    const int CT = tiles_per_wg(cin / 32), NT = tiles_per_wg(cout / 32);
+    dim3 grid((unsigned)nchunks, (unsigned)(cin / (32 * CT)), (unsigned)(cout / (32 * NT)));
+    int rc;
+    switch (CT) {
+      case 1: rc = launch_wg_nt<1>(NT, a, grid, st); break;
+      case 2: rc = launch_wg_nt<2>(NT, a, grid, st); break;
+      default: rc = launch_wg_nt<3>(NT, a, grid, st); break;
+    }
+    if (rc) return rc;
+  }
+  wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per_k, 256), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
+                                                                                      per_k, gweight);
+  PCMI_LAUNCH_CHECK();
+  if (gbias) {
+    float* part = (float*)((char*)ws + align_up(slab_bytes, 256));
+    const int nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n_out, 64)));
+    const int rows_per_block = (int)ceil_div(n_out, nblocks);
+    colsum_partial_kernel<<<nblocks, 256, 0, st>>>(gout, gout_ld, n_out, cout, rows_per_block, part);
+    PCMI_LAUNCH_CHECK();
+    colsum_final_kernel<<<dim3((unsigned)ceil_div(cout, 256)), 256, 0, st>>>(part, nblocks, cout, gbias);
+    PCMI_LAUNCH_CHECK();
+  }
+  return PCMI_OK;
+}
+
+}  // extern "C"

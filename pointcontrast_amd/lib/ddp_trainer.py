@@ -1,0 +1,255 @@
+"""Training step of the contrastive pre-training (pc/lib/ddp_trainer.py), on libpcmi.
+
+Same classes and control flow as the reference -- ContrastiveLossTrainer,
+HardestContrastiveLossTrainer (:171-326), PointNCELossTrainer (:328-440), `_train_iter`,
+checkpoint layout (:151-169) -- with these deliberate differences:
+  * every sparse op, both losses and the optimiser are libpcmi HIP kernels (no ME, no torch
+    conv / mm / CrossEntropy / SGD kernels);
+  * DDP is FlatParameters + GradReducer (RCCL buckets on a side stream) instead of
+    torch DistributedDataParallel; BN buffers stay per-rank (broadcast_buffers=False, :101);
+  * the host-RNG draws of the reference (np.random.choice, Uniform.sample) can be injected
+    (`draws=`) so that parity tests feed the oracle the same index sets;
+  * `_train_iter` returns the loss as a 0-dim device tensor; `.item()` happens only when the
+    loop logs (stat_freq), so the host never waits on the GPU inside an iteration
+    (the reference syncs every iteration at :316-318,433);
+  * no torch.cuda.empty_cache() per iteration (:321,437) and no autograd anomaly mode (:36).
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from .. import functional as PF
+from .. import minkowski as ME
+from ..model import load_model
+from . import distributed as du
+from .solver import FlatSGD
+from .timer import AverageMeter, Timer
+
+
+def _hash(arr, M):
+  """int64 key of index tuples (pc/lib/ddp_trainer.py:39-51); kept for host-side checks."""
+  if isinstance(arr, np.ndarray):
+    N, D = arr.shape
+    cols = [arr[:, d] for d in range(D)]
+  else:
+    N, D = len(arr[0]), len(arr)
+    cols = arr
+  hv = np.zeros(N, dtype=np.int64)
+  for d in range(D):
+    hv += np.asarray(cols[d], dtype=np.int64) * np.int64(M) ** d
+  return hv
+
+
+def load_state(model, weights, lenient_weight_loading=False):
+  if lenient_weight_loading:
+    own = model.state_dict()
+    keep = {k: v for k, v in weights.items() if k in own and v.size() == own[k].size()}
+    logging.info("Load weights:" + ", ".join(keep.keys()))
+    own.update(keep)
+    weights = own
+  model.load_state_dict(weights, strict=True)
+
+
+class ContrastiveLossTrainer:
+
+  def __init__(self, config, data_loader):
+    assert config.misc.use_gpu and torch.cuda.is_available(), "the pre-training path runs on a gfx950 GPU"
+    num_feats = 3  # ones (+ jitter), pc/lib/ddp_data_loaders.py:248-252
+    self.config = config
+    self.world_size = du.get_world_size()
+    self.is_master = du.is_master_proc()
+    self.cur_device = torch.device("cuda", torch.cuda.current_device())
+
+    Model = load_model(config.net.model)
+    model = Model(num_feats, config.net.model_n_out, config, D=3).to(self.cur_device)
+    if self.world_size > 1:  # what DDP's constructor does: rank 0's parameters everywhere
+      for p in model.parameters():
+        torch.distributed.broadcast(p.data, src=0)
+    self.model = model
+    self.flat = du.FlatParameters(model.parameters())
+    self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", 32.0))
+    self.optimizer = FlatSGD(self.flat, lr=config.opt.lr, momentum=config.opt.momentum,
+                             weight_decay=config.opt.weight_decay, grad_scale=self.reducer.grad_scale)
+    self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, config.opt.exp_gamma)
+    self.curr_iter = 0
+    self.batch_size = data_loader.batch_size if data_loader is not None else config.trainer.batch_size
+    self.data_loader = data_loader
+    self.neg_thresh, self.pos_thresh = config.trainer.neg_thresh, config.trainer.pos_thresh
+    self.stat_freq, self.lr_update_freq = config.trainer.stat_freq, config.trainer.lr_update_freq
+
+    if config.misc.weight:
+      state = torch.load(config.misc.weight, map_location="cpu", weights_only=False)
+      load_state(model, state["state_dict"], config.misc.lenient_weight_loading)
+    ckpt = "weights/weights.pth"
+    if os.path.isfile(ckpt):
+      state = torch.load(ckpt, map_location="cpu", weights_only=False)
+      self.curr_iter = state["curr_iter"]
+      load_state(model, state["state_dict"])
+      self.optimizer.load_state_dict(state["optimizer"])
+      self.scheduler.load_state_dict(state["scheduler"])
+      if self.is_master:
+        logging.info("=> loaded checkpoint '%s' (curr_iter %d)", ckpt, self.curr_iter)
+
+  # -- checkpoint: {curr_iter, state_dict, optimizer, scheduler, config} + weights.pth symlink ----
+  def _save_checkpoint(self, curr_iter, filename="checkpoint"):
+    if not self.is_master:
+      return
+    os.makedirs("weights", mode=0o755, exist_ok=True)
+    cfg = self.config.to_dict() if hasattr(self.config, "to_dict") else self.config
+    state = {"curr_iter": curr_iter, "state_dict": self.model.state_dict(), "optimizer": self.optimizer.state_dict(),
+             "scheduler": self.scheduler.state_dict(), "config": cfg}
+    path = os.path.join("weights", filename + ".pth")
+    logging.info("Saving checkpoint: %s ...", path)
+    torch.save(state, path)
+    link = "weights/weights.pth"
+    if os.path.lexists(link):
+      os.remove(link)
+    os.symlink(filename + ".pth", link)
+
+  # -- shared pieces of one iteration ----------------------------------------------------------
+  def _forward_pair(self, input_dict):
+    s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device)
+    F0 = self.model(s0).F
+    s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
+    F1 = self.model(s1).F
+    return F0, F1
+
+  def _backward_and_step(self, loss, result):
+    loss.backward()
+    self.reducer.finish()
+    if self.world_size > 1:
+      result = du.scaled_all_reduce_dict({k: v.detach().clone() for k, v in result.items()}, self.world_size)
+    self.optimizer.step()
+    return result
+
+  def train(self):
+    curr_iter = self.curr_iter
+    it = iter(self.data_loader)
+    data_meter, data_timer, total_timer = AverageMeter(), Timer(), Timer()
+    while curr_iter < self.config.opt.max_iter:
+      curr_iter += 1
+      epoch = curr_iter / max(len(self.data_loader), 1)
+      result = self._train_iter(it, [data_meter, data_timer, total_timer])
+      if curr_iter % self.lr_update_freq == 0 or curr_iter == 1:
+        lr = self.scheduler.get_last_lr()
+        self.scheduler.step()
+        if self.is_master:
+          logging.info(" Epoch: %s, LR: %s", epoch, lr)
+          self._save_checkpoint(curr_iter, "checkpoint_" + str(curr_iter))
+      if curr_iter % self.stat_freq == 0 and self.is_master:
+        vals = {k: float(v) for k, v in (result.items() if isinstance(result, dict) else [("loss", result)])}
+        logging.info("Train Epoch: %.3f [%d/%d], Current Loss: %.3e %s\tData time: %.4f, Train time: %.4f, "
+                     "Iter time: %.4f, LR: %s", epoch, curr_iter, len(self.data_loader), vals["loss"],
+                     {k: round(v, 5) for k, v in vals.items() if k != "loss"}, data_meter.avg,
+                     total_timer.avg - data_meter.avg, total_timer.avg, self.scheduler.get_last_lr())
+        data_meter.reset()
+        total_timer.reset()
+    self.curr_iter = curr_iter
+
+
+class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
+
+  def contrastive_hardest_negative_loss(self, F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048,
+                                        draws=None):
+    """pc/lib/ddp_trainer.py:186-238.  positive_pairs: CPU int tensor / array [P,2].
+    draws: optional dict(sel0, sel1, pos_sel) replacing the np.random.choice calls."""
+    N0, N1 = F0.shape[0], F1.shape[0]
+    pp = positive_pairs.numpy() if torch.is_tensor(positive_pairs) else np.asarray(positive_pairs)
+    P = len(pp)
+    hash_seed = max(N0, N1)
+    draws = draws or {}
+    sel0 = draws["sel0"] if "sel0" in draws else np.random.choice(N0, min(N0, num_hn_samples), replace=False)
+    sel1 = draws["sel1"] if "sel1" in draws else np.random.choice(N1, min(N1, num_hn_samples), replace=False)
+    if "pos_sel" in draws:
+      pos_sel = draws["pos_sel"]
+    else:
+      pos_sel = np.random.choice(P, num_pos, replace=False) if P > num_pos else None
+    sample = pp if pos_sel is None else pp[np.asarray(pos_sel)]
+    dev = F0.device
+    up = lambda a, dt=torch.int64: torch.as_tensor(np.ascontiguousarray(a)).to(dev, dtype=dt, non_blocking=True)
+    sel0_d, sel1_d = up(sel0), up(sel1)
+    pos0_d, pos1_d = up(sample[:, 0]), up(sample[:, 1])
+    pairs_d = up(pp, torch.int32)
+
+    subF0, subF1 = PF.GatherRowsFunction.apply(F0, sel0_d), PF.GatherRowsFunction.apply(F1, sel1_d)
+    posF0, posF1 = PF.GatherRowsFunction.apply(F0, pos0_d), PF.GatherRowsFunction.apply(F1, pos1_d)
+    with torch.no_grad():
+      D01min, D01ind = PF.pdist_argmin(posF0, subF1)
+      D10min, D10ind = PF.pdist_argmin(posF1, subF0)
+      keys = PF.PairKeySet(pairs_d, hash_seed)
+      neg1 = sel1_d[D01ind.long()]  # row of F1 mined for each posF0
+      neg0 = sel0_d[D10ind.long()]
+      mask0 = keys.absent(pos0_d, neg1)
+      mask1 = keys.absent(neg0, pos1_d)
+    losses = PF.HardestLossFunction.apply(posF0, posF1, subF0, subF1, D01min, D01ind, mask0, D10min, D10ind, mask1,
+                                          self.pos_thresh, self.neg_thresh)
+    self._last_mined = dict(D01ind=D01ind, D10ind=D10ind, mask0=mask0, mask1=mask1)
+    return losses[0], losses[1]
+
+  def _train_iter(self, data_loader_iter, timers, draws=None):
+    self.model.train()
+    data_meter, data_timer, total_timer = timers
+    self.optimizer.zero_grad()
+    total_timer.tic()
+    data_timer.tic()
+    input_dict = next(data_loader_iter)
+    data_time = data_timer.toc(average=False)
+    F0, F1 = self._forward_pair(input_dict)
+    pos_loss, neg_loss = self.contrastive_hardest_negative_loss(
+        F0, F1, input_dict["correspondences"],
+        num_pos=self.config.trainer.num_pos_per_batch * self.batch_size,
+        num_hn_samples=self.config.trainer.num_hn_samples_per_batch * self.batch_size, draws=draws)
+    loss = pos_loss + neg_loss
+    result = self._backward_and_step(loss, {"loss": loss.detach(), "pos_loss": pos_loss.detach(),
+                                            "neg_loss": neg_loss.detach()})
+    total_timer.toc()
+    data_meter.update(data_time)
+    return result
+
+
+class PointNCELossTrainer(ContrastiveLossTrainer):
+
+  def __init__(self, config, data_loader):
+    super().__init__(config, data_loader)
+    self.T, self.npos = config.misc.nceT, config.misc.npos
+
+  @staticmethod
+  def select_pairs(pos_pairs, npos, draws=None):
+    """One key per unique query voxel, optional npos sub-sample
+    (pc/lib/ddp_trainer.py:403-417).  The reference runs unique / cumsum on the GPU and the
+    RNG on the host; the correspondences arrive on the host anyway, so the whole selection
+    is host-side here (identical arithmetic: fp32 floor(u * count)) and only the two index
+    vectors are uploaded."""
+    pp = pos_pairs if torch.is_tensor(pos_pairs) else torch.as_tensor(np.asarray(pos_pairs))
+    pp = pp.long().cpu()
+    q_unique, count = pp[:, 0].unique(return_counts=True)
+    draws = draws or {}
+    uniform = draws["uniform"] if "uniform" in draws else torch.distributions.Uniform(0, 1).sample([len(count)])
+    off = torch.floor(torch.as_tensor(uniform, dtype=torch.float32) * count).long()
+    cums = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(count, dim=0)[:-1]])
+    k_sel = pp[:, 1][off + cums]
+    if npos < q_unique.shape[0]:
+      si = draws["sampled_inds"] if "sampled_inds" in draws else np.random.choice(q_unique.shape[0], npos, replace=False)
+      si = torch.as_tensor(np.asarray(si)).long()
+      q_unique, k_sel = q_unique[si], k_sel[si]
+    return q_unique, k_sel
+
+  def _train_iter(self, data_loader_iter, timers, draws=None):
+    self.model.train()
+    data_meter, data_timer, total_timer = timers
+    self.optimizer.zero_grad()
+    total_timer.tic()
+    data_timer.tic()
+    input_dict = next(data_loader_iter)
+    data_time = data_timer.toc(average=False)
+    F0, F1 = self._forward_pair(input_dict)
+    q_idx, k_idx = self.select_pairs(input_dict["correspondences"], self.npos, draws)
+    q = PF.GatherRowsFunction.apply(F0, q_idx.to(self.cur_device, non_blocking=True))
+    k = PF.GatherRowsFunction.apply(F1, k_idx.to(self.cur_device, non_blocking=True))
+    loss = PF.NCELossFunction.apply(q, k, self.T)
+    result = self._backward_and_step(loss, {"loss": loss.detach()})
+    total_timer.toc()
+    data_meter.update(data_time)
+    return result

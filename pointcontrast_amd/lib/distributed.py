@@ -1,0 +1,156 @@
+"""Process-group helpers and the overlapped gradient all-reduce.
+
+Live surface of pc/lib/distributed.py (init_process_group :143-153, destroy :155-157,
+get_world_size :21-26, is_master_proc :132-140, scaled_all_reduce_dict :260-270) plus
+what the reference gets from torch DistributedDataParallel (pc/lib/ddp_trainer.py:96-102):
+bucketed gradient all-reduce overlapped with backward.  Here the gradients live in ONE flat
+fp32 buffer; buckets are contiguous slices taken from its end (= the order backward produces
+them); a bucket is all-reduced with RCCL on a side HIP stream as soon as its last gradient
+has been accumulated; the 1/world scale is folded into the fused SGD step.
+One process per GPU (torchrun / RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* from the environment).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def get_world_size():
+  return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+  return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_master_proc(num_gpus=None):
+  return get_world_size() == 1 or get_rank() == 0
+
+
+def init_process_group(proc_rank=None, world_size=None, backend=None):
+  """nccl (= RCCL on ROCm) when CUDA is available, gloo otherwise.  Rendezvous through the
+  MASTER_ADDR / MASTER_PORT environment (127.0.0.1 single node), not the reference's fixed
+  tcp://localhost:10001."""
+  rank = int(os.environ.get("RANK", 0)) if proc_rank is None else proc_rank
+  world = int(os.environ.get("WORLD_SIZE", 1)) if world_size is None else world_size
+  use_cuda = torch.cuda.is_available()
+  if use_cuda:
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1))
+  os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+  os.environ.setdefault("MASTER_PORT", "29500")
+  dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+  return rank, world
+
+
+def destroy_process_group():
+  if dist.is_initialized():
+    dist.destroy_process_group()
+
+
+def scaled_all_reduce_dict(res_dict, num_gpus):
+  """Mean over ranks of every 0-dim tensor of the dict (logging only)."""
+  works = [dist.all_reduce(res_dict[k], async_op=True) for k in res_dict]
+  for w in works:
+    w.wait()
+  return {k: v.clone().mul_(1.0 / num_gpus) for k, v in res_dict.items()}
+
+
+class FlatParameters:
+  """All trainable parameters, their gradients and the SGD momentum as three flat fp32
+  buffers; every nn.Parameter's .data / .grad become views (16-byte aligned slices)."""
+
+  def __init__(self, params):
+    self.params = [p for p in params if p.requires_grad]
+    dev = self.params[0].device
+    self.offsets, total = [], 0
+    for p in self.params:
+      self.offsets.append(total)
+      total += (p.numel() + 3) // 4 * 4
+    self.numel = total
+    self.w = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.g = torch.zeros(total, dtype=torch.float32, device=dev)
+    self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+      for p, off in zip(self.params, self.offsets):
+        n = p.numel()
+        self.w[off:off + n].copy_(p.data.reshape(-1))
+        p.data = self.w[off:off + n].view(p.shape)
+        p.grad = self.g[off:off + n].view(p.shape)
+
+  def view(self, buf, i):
+    p, off = self.params[i], self.offsets[i]
+    return buf[off:off + p.numel()].view(p.shape)
+
+  def zero_grad(self):
+    self.g.zero_()
+    for i, p in enumerate(self.params):  # a set_to_none elsewhere must not detach the views
+      if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * self.offsets[i]:
+        p.grad = self.view(self.g, i)
+
+
+class GradReducer:
+  """Bucketed all-reduce(SUM) of FlatParameters.g overlapped with backward."""
+
+  def __init__(self, flat, bucket_mb=32.0, process_group=None):
+    self.flat, self.pg = flat, process_group
+    self.world = get_world_size()
+    self.cuda = flat.g.is_cuda
+    self.comm_stream = torch.cuda.Stream(device=flat.g.device) if self.cuda else None
+    cap = int(bucket_mb * (1 << 20) / 4)
+    # buckets from the END of the buffer: backward reaches the last layers first
+    self.buckets, self.bucket_of = [], {}
+    hi = flat.numel
+    members = []
+    for i in range(len(flat.params) - 1, -1, -1):
+      members.append(i)
+      lo = flat.offsets[i]
+      if hi - lo >= cap or i == 0:
+        b = len(self.buckets)
+        self.buckets.append((lo, hi, len(members)))
+        for m in members:
+          self.bucket_of[m] = b
+        members, hi = [], lo
+    self._pending = [0] * len(self.buckets)
+    self._works = []
+    self._hooks = []
+    if self.world > 1:
+      for i, p in enumerate(flat.params):
+        self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+  def _make_hook(self, i):
+    def hook(_p):
+      b = self.bucket_of[i]
+      self._pending[b] += 1
+      if self._pending[b] == self.buckets[b][2]:
+        self._launch(b)
+    return hook
+
+  def _launch(self, b):
+    lo, hi, _ = self.buckets[b]
+    chunk = self.flat.g[lo:hi]
+    if self.cuda:
+      ev = torch.cuda.Event()
+      ev.record(torch.cuda.current_stream(chunk.device))
+      self.comm_stream.wait_event(ev)
+      with torch.cuda.stream(self.comm_stream):
+        self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+    else:
+      self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+
+  def finish(self):
+    """Call after backward: launches what is left and makes the compute stream wait for RCCL."""
+    if self.world == 1:
+      return
+    for b, cnt in enumerate(self._pending):
+      if cnt != self.buckets[b][2]:  # parameters that received no gradient this step
+        self._launch(b)
+    for w in self._works:
+      w.wait()
+    if self.cuda:
+      torch.cuda.current_stream(self.flat.g.device).wait_stream(self.comm_stream)
+    self._works = []
+    self._pending = [0] * len(self.buckets)
+
+  @property
+  def grad_scale(self):
+    return 1.0 / self.world
