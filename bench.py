@@ -1,0 +1,291 @@
+"""Benchmark of the PointContrast pre-training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+          --master-port P bench.py --gpus N --steps K --warmup W)
+
+Metric (BASELINE.json): scene-pairs/sec of the full training iteration -- 2 forwards of
+Res16UNet34C, PointInfoNCE (or HardestContrastive with --loss hardest), backward, gradient
+all-reduce (N > 1), SGD step -- on seeded synthetic ScanNet-shaped pairs (2.5 cm voxels,
+B = 4 pairs per GPU, ~85k voxels per forward, 4096 correspondences), inputs staged on the host
+in the reference's batch format before the timed region starts (coordinates / features are
+uploaded inside the step exactly as the reference's ME.SparseTensor(...).to(device) does).
+One process per GPU, weak scaling: every rank has its own 4 pairs (seed = rank).
+
+Rank 0 prints ONE JSON line; besides the contract keys it carries
+  roofline     : the dominant kernel (fp32-MFMA gather-GEMM of the level-1 96->96 block conv)
+                 timed live with HIP events, algorithmic FLOPs / launch time vs the 157.3 TFLOP/s
+                 fp32 matrix peak (MI355X_MICROARCH.md); `kernels` lists the other hot kernels
+                 incl. the HBM-bound ones against the 8 TB/s peak
+  cpu_baseline : the CPU oracle's identical iteration on a bounded sample (1 pair), N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def get_batch(seed, batch_size, voxel_size):
+  """Seeded synthetic batch in the reference's collate format, cached on local disk."""
+  import torch
+  from pointcontrast_amd.lib import synthetic
+  cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pcmi_bench_cache")
+  os.makedirs(cache, exist_ok=True)
+  path = os.path.join(cache, "s%d_b%d_v%g.npz" % (seed, batch_size, voxel_size))
+  keys = ["sinput0_C", "sinput0_F", "sinput1_C", "sinput1_F", "correspondences"]
+  if os.path.exists(path):
+    z = np.load(path)
+    d = {k: z[k] for k in keys}
+  else:
+    d = synthetic.make_batch(seed=seed, batch_size=batch_size, voxel_size=voxel_size)
+    np.savez(path, **{k: d[k] for k in keys})
+  return {k: torch.from_numpy(np.ascontiguousarray(d[k])) for k in keys}
+
+
+def conv_work(model):
+  """Algorithmic FLOPs / bytes of one forward from the real per-layer pair counts
+  (flops = 2*M*Cin*Cout; bytes = M*(4*Cin + 8) + N_out*4*Cout + 4*K*Cin*Cout)."""
+  from pointcontrast_amd.minkowski import _ConvBase
+  flops = bytes_ = 0
+  rows = []
+  for name, m in model.named_modules():
+    if isinstance(m, _ConvBase) and hasattr(m, "last_work"):
+      M, n_in, n_out, K = m.last_work
+      f = 2 * M * m.in_channels * m.out_channels
+      b = M * (4 * m.in_channels + 8) + n_out * 4 * m.out_channels + 4 * K * m.in_channels * m.out_channels
+      flops += f
+      bytes_ += b
+      rows.append((name, K, m.in_channels, m.out_channels, int(M), int(n_out), f, b))
+  return flops, bytes_, rows
+
+
+def time_kernel(fn, iters=20, warm=3):
+  import torch
+  for _ in range(warm):
+    fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()  # libpcmi launches on torch's current stream, the stream these events are recorded on
+  for _ in range(iters):
+    fn()
+  e1.record()
+  e1.synchronize()
+  return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_rooflines(batch, device):
+  """Times the hot kernels in isolation on the level-1 map of cloud 0 (HIP events)."""
+  import torch
+  import pointcontrast_amd.minkowski as ME
+  from pointcontrast_amd import functional as PF
+  from pointcontrast_amd._lib import lib, check
+  from pointcontrast_amd.runtime import ptr, cur_stream, ws_args
+  import ctypes as C
+  st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(device)
+  cm, key = st.coords_man, st.coords_key
+  n = st.F.shape[0]
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  out = []
+
+  def conv_entry(label, cin, cout, kmap, K, n_in, n_out, transpose=False, mode="fwd"):
+    W = torch.randn((K, cin, cout) if K > 1 else (cin, cout), device=device) * 0.05
+    x = torch.randn(n_in, cin, device=device)
+    g = torch.randn(n_out, cout, device=device)
+    M = kmap.M if kmap is not None else n_in
+    y = torch.empty(n_out, cout, device=device)
+    gin = torch.empty(n_in, cin, device=device)
+    gw = torch.empty_like(W)
+    ws, wsb = ws_args(lib.pcmi_spconv_workspace_bytes(n_in, n_out, cin, cout, K, M), device)
+    kref = C.byref(kmap) if kmap is not None else None
+    s = cur_stream(device)
+    if mode == "fwd":
+      fn = lambda: check(lib.pcmi_spconv_fwd(ptr(x), cin, n_in, cin, ptr(W), cout, kref, int(transpose), None, ptr(y),
+                                             cout, n_out, ws, wsb, s))
+      byts = M * (4 * cin + 8) + n_out * 4 * cout + 4 * K * cin * cout
+    elif mode == "bwd_data":
+      fn = lambda: check(lib.pcmi_spconv_bwd_data(ptr(g), cout, n_out, cout, ptr(W), cin, kref, int(transpose), ptr(gin),
+                                                  cin, n_in, ws, wsb, s))
+      byts = M * (4 * cout + 8) + n_in * 4 * cin + 4 * K * cin * cout
+    else:
+      fn = lambda: check(lib.pcmi_spconv_bwd_weight(ptr(x), cin, n_in, cin, ptr(g), cout, n_out, cout, kref,
+                                                    int(transpose), ptr(gw), None, ws, wsb, s))
+      byts = M * 4 * (cin + cout) + 8 * M + 4 * K * cin * cout
+    t = time_kernel(fn)
+    flops = 2 * M * cin * cout
+    intensity = flops / byts
+    bound = "mfma" if intensity > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    ent = {"kernel": label, "ms": round(t * 1e3, 4), "pairs": int(M), "gflop": round(flops * 1e-9, 3),
+           "algo_mb": round(byts * 1e-6, 2), "bound": bound}
+    if bound == "mfma":
+      ent.update(achieved=round(flops / t * 1e-12, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s")
+    else:
+      ent.update(achieved=round(byts / t * 1e-9, 1), peak=PEAK_HBM_GBS, unit="GB/s")
+    ent["frac"] = round(ent["achieved"] / ent["peak"], 4)
+    out.append(ent)
+    return ent
+
+  dominant = conv_entry("spconv_mfma fwd 3^3 96->96 @level1", 96, 96, m, 27, n, n)
+  conv_entry("spconv_mfma bwd_data 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_data")
+  conv_entry("wgrad_mfma 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
+  conv_entry("spconv_mfma fwd 3^3 128->96 @level1", 128, 96, m, 27, n, n)
+  ck = cm.stride(key, 2)
+  m2 = cm.kernel_map(key, ck, 2, 2, 0)
+  conv_entry("spconv_mfma fwd 2^3/s2 32->32 (gather)", 32, 32, m2, 8, m2.n_in, m2.n_out)
+  conv_entry("spconv_mfma pair fwd 2^3/s2^T 96->96 (scatter)", 96, 96, m2, 8, m2.n_out, m2.n_in, transpose=True)
+  m1 = cm.kernel_map(ck, ck, 3, 1, 3)
+  conv_entry("spconv_mfma fwd 3^3 32->32 @level2", 32, 32, m1, 27, m2.n_out, m2.n_out)
+  # BatchNorm (train) fused with ReLU on [n, 96]: 2 reads + 1 write of the activation
+  x = torch.randn(n, 96, device=device)
+  gam, bet = torch.ones(96, device=device), torch.zeros(96, device=device)
+  rm, rv = torch.zeros(96, device=device), torch.ones(96, device=device)
+  t = time_kernel(lambda: PF.BatchNormFunction.apply(x, gam, bet, rm, rv, 0.1, 1e-5, None, True))
+  byts = 12 * n * 96
+  out.append({"kernel": "bn_fwd_train+relu [n,96] (3 kernels)", "ms": round(t * 1e3, 4), "algo_mb": round(byts * 1e-6, 2),
+              "bound": "hbm", "achieved": round(byts / t * 1e-9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+              "frac": round(byts / t * 1e-9 / PEAK_HBM_GBS, 4)})
+  return dominant, out
+
+
+def cpu_baseline(batch_size_sample=1):
+  """The CPU oracle's identical iteration (Res16UNet34C, PointInfoNCE, SGD) on `batch_size_sample`
+  synthetic pairs: one untimed + one timed iteration, all host cores."""
+  import torch
+  from oracle import loss_ref as lr, model_ref as mr, sparse_ref as sr
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  b = get_batch(seed=0, batch_size=batch_size_sample, voxel_size=0.025)
+  torch.manual_seed(0)
+  model = mr.Res16UNet34CRef(3, 32)
+  model.train()
+  opt = lr.make_sgd(model.parameters(), 0.1)
+  pp = b["correspondences"].numpy()
+  nq = len(np.unique(pp[:, 0]))
+  rng = np.random.RandomState(0)
+  times = []
+  for it in range(2):
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    F0 = model(sr.SparseTensorRef(b["sinput0_F"], coords=b["sinput0_C"].numpy())).F
+    F1 = model(sr.SparseTensorRef(b["sinput1_F"], coords=b["sinput1_C"].numpy())).F
+    si = rng.choice(nq, 4096, replace=False) if nq > 4096 else None
+    qi, ki = lr.nce_select_pairs(pp, torch.rand(nq), si)
+    loss = lr.nce_loss(F0, F1, qi, ki, 0.4)
+    loss.backward()
+    opt.step()
+    times.append(time.perf_counter() - t0)
+  return {"value": round(batch_size_sample / times[-1], 4), "unit": "scene-pairs/sec", "cores": torch.get_num_threads(),
+          "kind": "port",
+          "sample": "%d pair(s) (N0=%d, N1=%d voxels), full oracle iteration (2 fwd + NCE + bwd + SGD), 1 untimed + 1 timed"
+                    % (batch_size_sample, b["sinput0_C"].shape[0], b["sinput1_C"].shape[0])}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--batch", type=int, default=4, help="scene pairs per GPU (BASELINE config: 4)")
+  ap.add_argument("--voxel", type=float, default=0.025)
+  ap.add_argument("--loss", choices=["nce", "hardest"], default="nce")
+  ap.add_argument("--model", default="Res16UNet34C")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-roofline", action="store_true")
+  ap.add_argument("--layer-table", default=None, help="write the per-layer work table to this path")
+  args = ap.parse_args()
+
+  import torch
+  import torch.distributed as dist
+  assert torch.cuda.is_available(), "bench.py measures the HIP path and needs an MI355X (no CPU fallback)"
+  import __graft_entry__
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  if rank == 0:
+    __graft_entry__.build()
+  from pointcontrast_amd.lib import distributed as du
+  if world > 1:
+    du.init_process_group()
+    dist.barrier()
+  assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+  device = torch.device("cuda", torch.cuda.current_device())
+
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader
+  from pointcontrast_amd.lib import ddp_trainer
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  cfg = get_config(["net.model=%s" % args.model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1",
+                    "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world)])
+  batch = get_batch(seed=rank, batch_size=args.batch, voxel_size=args.voxel)
+  loader = FixedBatchLoader([batch], batch_size=args.batch)
+  torch.manual_seed(0)
+  np.random.seed(rank)
+  cls = ddp_trainer.PointNCELossTrainer if args.loss == "nce" else ddp_trainer.HardestContrastiveLossTrainer
+  trainer = cls(cfg, loader)
+  it = iter(loader)
+  timers = [AverageMeter(), Timer(), Timer()]
+
+  for _ in range(args.warmup):
+    res = trainer._train_iter(it, timers)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    res = trainer._train_iter(it, timers)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  loss_val = float(res["loss"])
+  if world > 1:
+    tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+
+  if rank == 0:
+    n0, n1 = batch["sinput0_C"].shape[0], batch["sinput1_C"].shape[0]
+    flops, byts, rows = conv_work(trainer.model)  # last forward = cloud 1
+    out = {
+        "metric": "scene-pairs/sec, ScanNet 2.5cm Res16UNet34C PointInfoNCE" if args.loss == "nce" else
+                  "scene-pairs/sec, ScanNet 2.5cm Res16UNet34C HardestContrastive",
+        "value": round(args.batch * world * args.steps / elapsed, 3), "unit": "scene-pairs/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[%d]: %s, %s loss, voxel %.3g m, %d pairs/GPU, %d+%d active voxels per "
+                               "forward pair on rank 0, npos 4096, T 0.4, SGD(lr 0.1, mom 0.8, wd 1e-4)"
+                               % (1 if args.loss == "nce" else 2, args.model, args.loss, args.voxel, args.batch, n0, n1),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
+                   "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3)},
+    }
+    if args.layer_table:
+      with open(args.layer_table, "w") as f:
+        f.write("layer\tK\tcin\tcout\tpairs\tn_out\tflops\talgo_bytes\n")
+        for r in rows:
+          f.write("\t".join(str(v) for v in r) + "\n")
+    if not args.no_roofline:
+      dom, kernels = kernel_rooflines(batch, device)
+      out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                         "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "ms": dom["ms"]}
+      out["kernels"] = kernels
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(1)
+    print(json.dumps(out), flush=True)
+  if world > 1:
+    dist.barrier()
+    du.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

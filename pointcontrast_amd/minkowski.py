@@ -323,6 +323,7 @@ class _ConvBase(nn.Module):
     assert cm is not None, "move the SparseTensor to the GPU first (.to(device))"
     if self.kernel_volume == 1 and self.stride == 1:
       out = PF.SparseConvFunction.apply(x.F, self.kernel, self.bias, None, False, x.F.shape[0], cm)
+      self.last_work = (x.F.shape[0], x.F.shape[0], x.F.shape[0], 1)  # (pairs, n_in, n_out, K)
       return SparseTensor(out, coords_key=in_key, coords_manager=cm)
     region = self.kernel_generator.region_code
     if self.transpose:
@@ -335,6 +336,7 @@ class _ConvBase(nn.Module):
       out_key = in_key
       kmap = cm.kernel_map(in_key, out_key, self.kernel_size, 1, region)
     n_out = kmap.n_in if self.transpose else kmap.n_out
+    self.last_work = (kmap.M, x.F.shape[0], n_out, kmap.K)
     out = PF.SparseConvFunction.apply(x.F, self.kernel, self.bias, kmap, self.transpose, n_out, cm)
     return SparseTensor(out, coords_key=out_key, coords_manager=cm)
 

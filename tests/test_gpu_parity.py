@@ -1,0 +1,602 @@
+"""GPU parity tests (pytest -m gpu, on a real MI355X): every libpcmi kernel against the CPU oracle
+on the same seeded inputs, the committed golden vectors, and -- at BASELINE.json's full sizes --
+size-independent properties (map symmetry, linearity, forward/backward adjointness).
+
+Tolerances: integer tables bit-exact; fp32 results max|err| <= 1e-4 * max|ref| (the
+north_star's 1e-4 relative) unless a test states otherwise.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_coords, surface_coords
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_small.npz"))
+DEV = "cuda:0"
+
+
+def rel_err(got, ref):
+  got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+  return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def assert_close(got, ref, tol=1e-4, what=""):
+  e = rel_err(got, ref)
+  assert e <= tol, "%s: rel err %.3e > %.1e (shape %s)" % (what, e, tol, tuple(ref.shape))
+
+
+@pytest.fixture(scope="module")
+def ME():
+  import pointcontrast_amd.minkowski as me
+  return me
+
+
+def _device_tensor(ME, coords, feats):
+  return ME.SparseTensor(torch.as_tensor(feats), coords=torch.as_tensor(coords)).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+# integer work: coordinates, strided levels, kernel maps (bit-exact)
+# ------------------------------------------------------------------------------------------------
+def _check_maps(ME, coords, levels):
+  from oracle import sparse_ref as sr
+  ref = sr.CoordsManagerRef(coords)
+  st = _device_tensor(ME, coords, np.zeros((len(coords), 4), np.float32))
+  cm, key, rkey = st.coords_man, st.coords_key, 0
+  for lvl in range(levels):
+    assert cm.size(key) == ref.size(rkey)
+    assert (cm.get_coords(key).cpu().numpy() == ref.coords[rkey]).all(), "coords level %d" % lvl
+    for region in (0, 3):
+      m = cm.kernel_map(key, key, 3, 1, region)
+      nbr, pin, pout = cm.export_map(m)
+      rm = ref.kernel_map(rkey, rkey, 3, region)
+      assert (nbr.cpu().numpy() == rm.nbr).all(), "nbr level %d region %d" % (lvl, region)
+      assert list(m.offs_host[:28]) == rm.offs.tolist()
+      assert m.M == rm.offs[-1]
+      assert (pin.cpu().numpy() == np.concatenate([p[0] for p in rm.pairs])).all()
+      assert (pout.cpu().numpy() == np.concatenate([p[1] for p in rm.pairs])).all()
+      off = sr.region_offsets(3, region)
+      for k in range(27):
+        assert (off[m.mirror[k]] == -off[k]).all()
+    ckey = cm.stride(key, 2)
+    rck = ref.stride(rkey, 2)
+    m2 = cm.kernel_map(key, ckey, 2, 2, 0)
+    nbr2, pin2, pout2 = cm.export_map(m2)
+    rm2 = ref.kernel_map(rkey, rck, 2)
+    assert (nbr2.cpu().numpy() == rm2.nbr).all(), "child table level %d" % lvl
+    assert (pin2.cpu().numpy() == np.concatenate([p[0] for p in rm2.pairs])).all()
+    assert (pout2.cpu().numpy() == np.concatenate([p[1] for p in rm2.pairs])).all()
+    assert m2.M == ref.size(rkey)
+    key, rkey = ckey, rck
+  return cm
+
+
+def test_maps_match_golden_fixture(ME):
+  coords = G["coords"]
+  st = _device_tensor(ME, coords, np.zeros((len(coords), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  for lvl in range(3):
+    for name, region in (("cube", 0), ("hybrid", 3)):
+      nbr, _, _ = cm.export_map(cm.kernel_map(key, key, 3, 1, region))
+      assert (nbr.cpu().numpy() == G["nbr_%s_l%d" % (name, lvl)]).all()
+    ck = cm.stride(key, 2)
+    assert (cm.get_coords(ck).cpu().numpy() == G["coords_l%d" % (lvl + 1)]).all()
+    m2 = cm.kernel_map(key, ck, 2, 2, 0)
+    nbr2, _, _ = cm.export_map(m2)
+    assert (nbr2.cpu().numpy() == G["child_l%d" % lvl]).all()
+    assert list(m2.offs_host[:9]) == G["s2_offs_l%d" % lvl].tolist()
+    key = ck
+
+
+@pytest.mark.parametrize("n_side,batch", [(6, 1), (40, 3)])
+def test_maps_match_oracle(ME, n_side, batch):
+  _check_maps(ME, surface_coords(n_side, batch, seed=n_side), levels=4)
+
+
+def test_maps_random_negative_coords(ME):
+  _check_maps(ME, random_coords(3000, extent=24, batch=4, seed=5), levels=3)
+
+
+def test_single_voxel_and_errors(ME):
+  from pointcontrast_amd._lib import PcmiError
+  cm = _check_maps(ME, np.array([[0, -5, 7, 3]], np.int32), levels=2)
+  assert cm.size(cm.key_at_stride(4)) == 1
+  dup = np.array([[0, 1, 2, 3], [0, 1, 2, 3]], np.int32)
+  with pytest.raises(PcmiError, match="duplicate"):
+    _device_tensor(ME, dup, np.zeros((2, 4), np.float32))
+  far = np.array([[0, 1 << 18, 0, 0]], np.int32)
+  with pytest.raises(PcmiError, match="range"):
+    _device_tensor(ME, far, np.zeros((1, 4), np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse convolution fwd / bwd-data / bwd-weight
+# ------------------------------------------------------------------------------------------------
+_COORD_SETS = {}
+
+
+def _coords(size):
+  if size not in _COORD_SETS:
+    if size == "tiny":
+      c = surface_coords(6, 1, seed=1)       # ~70 rows: RW=1, offset split
+    elif size == "small":
+      c = surface_coords(28, 2, seed=2)      # ~3k rows: RW=1
+    elif size == "mid":
+      c = surface_coords(72, 2, seed=3)      # ~20k rows: RW=2
+    else:
+      c = surface_coords(110, 2, seed=4)     # ~47k rows: RW=4
+    _COORD_SETS[size] = c
+  return _COORD_SETS[size]
+
+
+def _conv_case(ME, size, kind, cin, cout, bias=False, seed=0):
+  """Runs one conv through libpcmi and the oracle; returns dict of (got, ref) pairs."""
+  from oracle import model_ref as mr, sparse_ref as sr
+  from pointcontrast_amd.model.modules.common import ConvType, conv, conv_tr
+  coords = _coords(size)
+  g = torch.Generator().manual_seed(seed)
+  ref_cm = sr.CoordsManagerRef(coords)
+  st0 = _device_tensor(ME, coords, np.zeros((len(coords), 4), np.float32))
+  cm = st0.coords_man
+  if kind == "k3_hybrid":
+    mod = conv(cin, cout, 3, conv_type=ConvType.SPATIAL_HYPERCUBE_TEMPORAL_HYPERCROSS, bias=bias, D=3)
+    rmod = mr.ConvRef(cin, cout, 3, region=sr.HYBRID, bias=bias)
+    in_key, rin = st0.coords_key, 0
+  elif kind == "k3_cube":
+    mod = conv(cin, cout, 3, conv_type=ConvType.SPATIAL_HYPERCUBE, bias=bias, D=3)
+    rmod = mr.ConvRef(cin, cout, 3, region=sr.HYPERCUBE, bias=bias)
+    in_key, rin = st0.coords_key, 0
+  elif kind == "down":
+    mod = conv(cin, cout, 2, stride=2, conv_type=ConvType.SPATIAL_HYPERCUBE, D=3)
+    rmod = mr.ConvRef(cin, cout, 2, stride=2)
+    in_key, rin = st0.coords_key, 0
+  elif kind == "up":
+    mod = conv_tr(cin, cout, 2, upsample_stride=2, conv_type=ConvType.SPATIAL_HYPERCUBE, D=3)
+    rmod = mr.ConvRef(cin, cout, 2, stride=2, transpose=True)
+    in_key, rin = cm.stride(st0.coords_key, 2), ref_cm.stride(0, 2)
+  else:  # "1x1"
+    mod = conv(cin, cout, 1, bias=bias, D=3)
+    rmod = mr.ConvRef(cin, cout, 1, bias=bias)
+    in_key, rin = st0.coords_key, 0
+  mod.load_state_dict(rmod.state_dict())
+  mod = mod.to(DEV)
+  n_in = ref_cm.size(rin)
+  x = torch.randn(n_in, cin, generator=g)
+  xr = x.clone().requires_grad_(True)
+  xd = x.to(DEV).requires_grad_(cin >= 8)
+  yr = rmod(sr.SparseTensorRef(xr, coords_key=rin, coords_manager=ref_cm)).F
+  yd = mod(ME.SparseTensor(xd, coords_key=in_key, coords_manager=cm)).F
+  gy = torch.randn(yr.shape, generator=g)
+  yr.backward(gy)
+  yd.backward(gy.to(DEV))
+  out = {"out": (yd, yr), "gw": (mod.kernel.grad, rmod.kernel.grad)}
+  if cin >= 8:
+    out["gin"] = (xd.grad, xr.grad)
+  if bias:
+    out["gbias"] = (mod.bias.grad, rmod.bias.grad)
+  return out
+
+
+CONV_CASES = [
+    # (rows regime, kind, cin, cout)
+    ("tiny", "k3_hybrid", 32, 32), ("tiny", "k3_hybrid", 256, 256), ("tiny", "k3_cube", 128, 256),
+    ("tiny", "down", 128, 128), ("tiny", "up", 256, 256), ("tiny", "1x1", 128, 256), ("tiny", "k3_hybrid", 384, 256),
+    ("small", "k3_hybrid", 64, 64), ("small", "k3_hybrid", 192, 128), ("small", "k3_cube", 32, 64),
+    ("small", "down", 64, 64), ("small", "up", 256, 128), ("small", "1x1", 192, 128), ("small", "k3_hybrid", 96, 96),
+    ("mid", "k3_hybrid", 32, 32), ("mid", "k3_hybrid", 128, 96), ("mid", "down", 32, 32), ("mid", "up", 128, 96),
+    ("mid", "1x1", 128, 96),
+    ("big", "k3_hybrid", 96, 96), ("big", "k3_hybrid", 128, 96), ("big", "k3_cube", 32, 64), ("big", "down", 32, 32),
+    ("big", "up", 96, 96), ("big", "1x1", 96, 32), ("big", "k3_hybrid", 64, 128), ("big", "k3_hybrid", 32, 256),
+]
+
+
+@pytest.mark.parametrize("size,kind,cin,cout", CONV_CASES)
+def test_spconv_parity(ME, size, kind, cin, cout):
+  res = _conv_case(ME, size, kind, cin, cout, bias=(kind == "1x1"))
+  for name, (got, ref) in res.items():
+    assert_close(got, ref, 1e-4, "%s %s %d->%d %s" % (size, kind, cin, cout, name))
+
+
+@pytest.mark.parametrize("size", ["tiny", "mid", "big"])
+def test_stem_conv_parity(ME, size):
+  res = _conv_case(ME, size, "k3_cube", 3, 32)
+  for name, (got, ref) in res.items():
+    assert_close(got, ref, 1e-4, "stem %s %s" % (size, name))
+
+
+def test_spconv_golden(ME):
+  from pointcontrast_amd import functional as PF
+  st = _device_tensor(ME, G["coords"], G["x"])
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  y = PF.SparseConvFunction.apply(st.F, torch.from_numpy(G["W"]).to(DEV), None, m, False, len(G["coords"]), cm)
+  assert_close(y, torch.from_numpy(G["y_hybrid"]), 1e-5, "golden hybrid conv")
+  ck = cm.stride(key, 2)
+  m2 = cm.kernel_map(key, ck, 2, 2, 0)
+  W2 = torch.from_numpy(G["W2"]).to(DEV)
+  y2 = PF.SparseConvFunction.apply(st.F, W2, None, m2, False, m2.n_out, cm)
+  assert_close(y2, torch.from_numpy(G["y_down"]), 1e-5, "golden strided conv")
+  y3 = PF.SparseConvFunction.apply(y2, W2, None, m2, True, m2.n_in, cm)
+  assert_close(y3, torch.from_numpy(G["y_up"]), 1e-5, "golden transposed conv")
+
+
+# ------------------------------------------------------------------------------------------------
+# normalisation / elementwise
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c", [(1, 32), (77, 32), (5000, 96), (40000, 128), (3000, 256), (90000, 32)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_batchnorm_parity(n, c, fused):
+  from pointcontrast_amd import functional as PF
+  if n == 1:
+    pytest.skip("single-row batch norm is degenerate (var = 0) in torch too")
+  torch.manual_seed(n + c)
+  x = torch.randn(n, c) * 2.0 + 0.7
+  res = torch.randn(n, c) if fused else None
+  bn = torch.nn.BatchNorm1d(c, eps=1e-5, momentum=0.05)
+  with torch.no_grad():
+    bn.weight.uniform_(0.5, 1.5)
+    bn.bias.uniform_(-0.5, 0.5)
+  gamma, beta = bn.weight.detach().clone().to(DEV).requires_grad_(True), bn.bias.detach().clone().to(DEV).requires_grad_(True)
+  rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+  xr = x.clone().requires_grad_(True)
+  rr = res.clone().requires_grad_(True) if fused else None
+  yr = bn(xr)
+  if fused:
+    yr = torch.relu(yr + rr)
+  xd = x.to(DEV).requires_grad_(True)
+  rd = res.to(DEV).requires_grad_(True) if fused else None
+  yd = PF.BatchNormFunction.apply(xd, gamma, beta, rm, rv, 0.05, 1e-5, rd, fused)
+  gy = torch.randn(n, c)
+  yr.backward(gy)
+  yd.backward(gy.to(DEV))
+  assert_close(yd, yr, 1e-4, "bn y")
+  assert_close(rm, bn.running_mean, 1e-4, "running mean")
+  assert_close(rv, bn.running_var, 1e-4, "running var")
+  assert_close(xd.grad, xr.grad, 2e-4, "bn dx")
+  assert_close(gamma.grad, bn.weight.grad, 2e-4, "bn dgamma")
+  assert_close(beta.grad, bn.bias.grad, 2e-4, "bn dbeta")
+  if fused:
+    assert_close(rd.grad, rr.grad, 1e-6, "bn dres")
+
+
+def test_bn_eval_relu_add_l2norm():
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(0)
+  x = torch.randn(1234, 96)
+  y = torch.randn(1234, 96)
+  bn = torch.nn.BatchNorm1d(96).eval()
+  with torch.no_grad():
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2)
+  got = PF.batch_norm_eval(x.to(DEV), bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), bn.running_mean.to(DEV),
+                           bn.running_var.to(DEV), bn.eps)
+  assert_close(got, bn(x), 1e-5, "bn eval")
+  xd = x.to(DEV).requires_grad_(True)
+  r = PF.ReLUFunction.apply(xd)
+  r.backward(y.to(DEV))
+  assert torch.equal(r.cpu(), torch.relu(x)) and torch.equal(xd.grad.cpu(), y * (x > 0))
+  assert torch.equal(PF.AddFunction.apply(x.to(DEV), y.to(DEV)).cpu(), x + y)
+  for c in (32, 16, 96):
+    f = torch.randn(777, c)
+    fr = f.clone().requires_grad_(True)
+    fd = f.to(DEV).requires_grad_(True)
+    nr = fr / torch.norm(fr, p=2, dim=1, keepdim=True)
+    nd = PF.L2NormalizeFunction.apply(fd)
+    gy = torch.randn(777, c)
+    nr.backward(gy)
+    nd.backward(gy.to(DEV))
+    assert_close(nd, nr, 1e-6, "l2 fwd")
+    assert_close(fd.grad, fr.grad, 1e-5, "l2 bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# losses, optimiser
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,T", [(300, 0.4), (300, 0.07), (64, 0.4), (1, 0.4), (4096, 0.4), (4096, 0.07), (1000, 0.07)])
+def test_nce_parity(n, T):
+  from oracle import loss_ref as lr
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(n)
+  if n == 300:
+    q, k = torch.from_numpy(G["q"]), torch.from_numpy(G["k"])
+  else:
+    q = torch.nn.functional.normalize(torch.randn(n, 32), dim=1)
+    k = torch.nn.functional.normalize(q + 0.3 * torch.randn(n, 32), dim=1)
+  qr, kr = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+  idx = torch.arange(n)
+  lref = lr.nce_loss(qr, kr, idx, idx, T)
+  (lref * 1.7).backward()
+  qd, kd = q.to(DEV).requires_grad_(True), k.to(DEV).requires_grad_(True)
+  ld = PF.NCELossFunction.apply(qd, kd, T)
+  (ld * 1.7).backward()
+  assert abs(float(ld) - float(lref)) <= 1e-4 * max(abs(float(lref)), 1e-3), (float(ld), float(lref))
+  if n == 300:
+    assert abs(float(ld) - float(G["nce_T%s" % T])) <= 1e-4 * abs(float(G["nce_T%s" % T]))
+  assert_close(qd.grad, qr.grad, 2e-4, "nce dq")
+  assert_close(kd.grad, kr.grad, 2e-4, "nce dk")
+
+
+def test_gather_scatter_rows():
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(0)
+  src = torch.randn(500, 32)
+  idx = torch.randint(0, 500, (2000,))
+  sd = src.to(DEV).requires_grad_(True)
+  out = PF.GatherRowsFunction.apply(sd, idx)
+  assert torch.equal(out.cpu(), src[idx])
+  g = torch.randn(2000, 32)
+  out.backward(g.to(DEV))
+  ref = torch.zeros(500, 32).index_add_(0, idx, g)
+  assert_close(sd.grad, ref, 1e-5, "scatter add")
+
+
+def test_pdist_argmin_and_keyset():
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(0)
+  a, b = torch.randn(1000, 32), torch.randn(333, 32)
+  dmin, amin = PF.pdist_argmin(a.to(DEV), b.to(DEV))
+  D = torch.sqrt(((a.unsqueeze(1) - b.unsqueeze(0)) ** 2).sum(2) + 1e-7)
+  rmin, rind = D.min(1)
+  assert_close(dmin, rmin, 1e-5, "pdist min")
+  same = amin.cpu().long() == rind
+  # a different arg-min is acceptable only at an fp32 tie
+  assert (same | ((D[torch.arange(1000), amin.cpu().long()] - rmin).abs() < 1e-6)).all()
+  pairs = torch.stack([torch.randint(0, 5000, (20000,)), torch.randint(0, 7000, (20000,))], 1).int()
+  ks = PF.PairKeySet(pairs.to(DEV), 7000)
+  qa = torch.cat([pairs[:100, 0].long(), torch.randint(0, 5000, (400,))])
+  qb = torch.cat([pairs[:100, 1].long(), torch.randint(0, 7000, (400,))])
+  got = ks.absent(qa.to(DEV), qb.to(DEV)).cpu().numpy().astype(bool)
+  keys = (pairs[:, 0].long() + pairs[:, 1].long() * 7000).numpy()
+  ref = ~np.isin((qa + qb * 7000).numpy(), keys)
+  assert (got == ref).all() and not got[:100].any()
+
+
+def test_hardest_loss_parity():
+  from oracle import loss_ref as lr
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_trainer import HardestContrastiveLossTrainer
+  torch.manual_seed(3)
+  rng = np.random.RandomState(3)
+  N0, N1 = 3000, 2800
+  F0 = torch.nn.functional.normalize(torch.randn(N0, 32), dim=1)
+  F1 = torch.nn.functional.normalize(torch.cat([F0[:N1] + 0.2 * torch.randn(N1, 32)]), dim=1)
+  i = np.sort(rng.randint(0, N1, 6000))
+  pp = np.unique(np.stack([i, np.clip(i + rng.randint(-1, 2, 6000), 0, N1 - 1)], 1), axis=0)
+  draws = dict(sel0=rng.choice(N0, 512, replace=False), sel1=rng.choice(N1, 512, replace=False),
+               pos_sel=rng.choice(len(pp), 1024, replace=False))
+  F0r, F1r = F0.clone().requires_grad_(True), F1.clone().requires_grad_(True)
+  pos_r, neg_r, aux = lr.hardest_contrastive_loss(F0r, F1r, pp, draws["sel0"], draws["sel1"], draws["pos_sel"])
+  (pos_r + neg_r).backward()
+  tr = HardestContrastiveLossTrainer.__new__(HardestContrastiveLossTrainer)
+  tr.pos_thresh, tr.neg_thresh = 0.1, 1.4
+  F0d, F1d = F0.to(DEV).requires_grad_(True), F1.to(DEV).requires_grad_(True)
+  pos_d, neg_d = tr.contrastive_hardest_negative_loss(F0d, F1d, pp, 1024, 512, draws)
+  (pos_d + neg_d).backward()
+  mined = tr._last_mined
+  agree = (mined["D01ind"].cpu().numpy() == aux["D01ind"]).mean()
+  assert agree > 0.995, agree  # arg-min can differ only at fp32 ties
+  assert (mined["mask0"].cpu().numpy().astype(bool) == aux["mask0"]).mean() > 0.995
+  assert abs(float(pos_d) - float(pos_r)) <= 1e-4 * abs(float(pos_r)) + 1e-7
+  assert abs(float(neg_d) - float(neg_r)) <= 2e-4 * abs(float(neg_r))
+  assert_close(F0d.grad, F0r.grad, 5e-3, "hardest dF0")  # a flipped tie moves one row's gradient
+  assert_close(F1d.grad, F1r.grad, 5e-3, "hardest dF1")
+
+
+def test_sgd_step_matches_torch():
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(0)
+  w = torch.randn(100003)
+  p = torch.nn.Parameter(w.clone())
+  opt = torch.optim.SGD([p], lr=0.1, momentum=0.8, weight_decay=1e-4)
+  wd, vd = w.to(DEV), torch.zeros(100003, device=DEV)
+  for it in range(3):
+    g = torch.randn(100003)
+    p.grad = g.clone()
+    opt.step()
+    PF.sgd_step(wd, (2.0 * g).to(DEV), vd, 0.1, 0.8, 1e-4, grad_scale=0.5)
+  assert_close(wd, p.data, 1e-6, "sgd weights")
+  assert_close(vd, opt.state[p]["momentum_buffer"], 1e-6, "sgd momentum")
+
+
+# ------------------------------------------------------------------------------------------------
+# whole network + training iteration
+# ------------------------------------------------------------------------------------------------
+def _make_models(name, cfg, seed=0):
+  from oracle import model_ref as mr
+  from pointcontrast_amd.model import load_model
+  torch.manual_seed(seed)
+  ref = mr.MODELS[name](3, 32, bn_momentum=cfg.opt.bn_momentum, normalize_feature=True)
+  dev = load_model(name)(3, 32, cfg, D=3)
+  dev.load_state_dict(ref.state_dict())
+  return ref, dev.to(DEV)
+
+
+@pytest.mark.parametrize("name,crop,batch", [("Res16UNet14", 0.6, 1), ("Res16UNet34C", 0.9, 2)])
+def test_network_features_loss_and_grads(ME, name, crop, batch):
+  from oracle import loss_ref as lr, sparse_ref as sr
+  from pointcontrast_amd import functional as PF
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
+  cfg = get_config([])
+  ref, dev = _make_models(name, cfg)
+  ref.train()
+  dev.train()
+  b = synthetic.make_batch(seed=5, batch_size=batch, crop=crop)
+  fr, fd = [], []
+  for s in ("0", "1"):
+    C, F = b["sinput%s_C" % s], torch.from_numpy(b["sinput%s_F" % s])
+    fr.append(ref(sr.SparseTensorRef(F, coords=C)).F)
+    fd.append(dev(ME.SparseTensor(F, coords=torch.from_numpy(C)).to(DEV)).F)
+    assert_close(fd[-1], fr[-1], 1e-4, "%s features cloud %s" % (name, s))
+  npos = 512
+  qi, ki = PointNCELossTrainer.select_pairs(torch.from_numpy(b["correspondences"]), npos,
+                                            dict(uniform=torch.rand(len(np.unique(b["correspondences"][:, 0])), generator=torch.Generator().manual_seed(1)),
+                                                 sampled_inds=np.random.RandomState(1).choice(len(np.unique(b["correspondences"][:, 0])), npos, replace=False)))
+  lref = lr.nce_loss(fr[0], fr[1], qi, ki, 0.4)
+  lref.backward()
+  q = PF.GatherRowsFunction.apply(fd[0], qi.to(DEV))
+  k = PF.GatherRowsFunction.apply(fd[1], ki.to(DEV))
+  ld = PF.NCELossFunction.apply(q, k, 0.4)
+  ld.backward()
+  assert abs(float(ld) - float(lref)) <= 1e-4 * abs(float(lref)), (float(ld), float(lref))
+  worst = 0.0
+  rp, dp = dict(ref.named_parameters()), dict(dev.named_parameters())
+  gn_ref = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in rp.values()))
+  for nme, p in rp.items():
+    # per-tensor error relative to the global gradient scale (tiny-gradient tensors carry noise)
+    e = float((dp[nme].grad.cpu().double() - p.grad.double()).abs().max() / max(float(p.grad.abs().max()), 1e-3 * float(gn_ref) / len(rp) ** 0.5))
+    worst = max(worst, e)
+  assert worst <= 2e-3, "worst per-tensor gradient error %.3e" % worst
+  gd = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in dp.values())).item()
+  assert abs(gd - float(gn_ref)) <= 1e-3 * float(gn_ref)
+  # BN running statistics were updated twice (two forwards), identically
+  assert_close(dev.bn0.bn.running_mean, ref.bn0.bn.running_mean, 1e-4, "bn0 running mean")
+  assert_close(dev.block8[1].norm2.bn.running_var, ref.block8[1].norm2.bn.running_var, 1e-4, "block8 running var")
+
+
+@pytest.mark.parametrize("which", ["nce", "hardest"])
+def test_trainer_iteration_matches_oracle(which):
+  """Two full iterations (2 forwards, loss, backward, SGD) of the device trainer against the
+  oracle model + torch.optim.SGD with the same injected random draws."""
+  from oracle import loss_ref as lr, sparse_ref as sr
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader, default_collate_pair_fn
+  from pointcontrast_amd.lib import ddp_trainer
+  cfg = get_config(["net.model=Res16UNet14", "misc.nceT=0.4", "misc.npos=256", "opt.lr=0.1",
+                    "trainer.num_pos_per_batch=256", "trainer.num_hn_samples_per_batch=128"])
+  rng = np.random.RandomState(9)
+  batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.7) for _ in range(2)])
+  loader = FixedBatchLoader([batch], batch_size=2)
+  torch.manual_seed(4)
+  cls = ddp_trainer.PointNCELossTrainer if which == "nce" else ddp_trainer.HardestContrastiveLossTrainer
+  trainer = cls(cfg, loader)
+  from oracle import model_ref as mr
+  ref = mr.MODELS["Res16UNet14"](3, 32, bn_momentum=cfg.opt.bn_momentum)
+  ref.load_state_dict({k: v.cpu() for k, v in trainer.model.state_dict().items()})
+  ref.train()
+  opt = lr.make_sgd(ref.parameters(), 0.1)
+  it = iter(loader)
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  timers = [AverageMeter(), Timer(), Timer()]
+  pp = batch["correspondences"].numpy()
+  nq = len(np.unique(pp[:, 0]))
+  N0, N1 = batch["sinput0_C"].shape[0], batch["sinput1_C"].shape[0]
+  for step in range(2):
+    r = np.random.RandomState(step)
+    if which == "nce":
+      draws = dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(step)),
+                   sampled_inds=r.choice(nq, 256, replace=False))
+    else:
+      draws = dict(sel0=r.choice(N0, 256, replace=False), sel1=r.choice(N1, 256, replace=False),
+                   pos_sel=r.choice(len(pp), 512, replace=False))
+    res = trainer._train_iter(it, timers, draws=draws)
+    opt.zero_grad()
+    F0 = ref(sr.SparseTensorRef(batch["sinput0_F"], coords=batch["sinput0_C"].numpy())).F
+    F1 = ref(sr.SparseTensorRef(batch["sinput1_F"], coords=batch["sinput1_C"].numpy())).F
+    if which == "nce":
+      qi, ki = lr.nce_select_pairs(pp, draws["uniform"], draws["sampled_inds"])
+      loss = lr.nce_loss(F0, F1, qi, ki, 0.4)
+    else:
+      pos, neg, _ = lr.hardest_contrastive_loss(F0, F1, pp, draws["sel0"], draws["sel1"], draws["pos_sel"])
+      loss = pos + neg
+    loss.backward()
+    opt.step()
+    tol = 1e-4 if which == "nce" else 1e-3
+    assert abs(float(res["loss"]) - float(loss)) <= tol * abs(float(loss)), (step, float(res["loss"]), float(loss))
+  worst = 0.0
+  dsd = trainer.model.state_dict()
+  for k, v in ref.state_dict().items():
+    if v.dtype.is_floating_point:
+      worst = max(worst, rel_err(dsd[k], v))
+  assert worst <= (2e-3 if which == "nce" else 2e-2), "state after 2 steps: worst rel err %.3e" % worst
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (no oracle needed): BASELINE config #2 shape, ~85k voxels per cloud
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_batch():
+  from pointcontrast_amd.lib import synthetic
+  return synthetic.make_batch(seed=0, batch_size=4, voxel_size=0.025)
+
+
+def test_full_size_map_properties(ME, full_batch):
+  C = full_batch["sinput0_C"]
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  n = len(C)
+  assert n > 60000
+  for region in (0, 3):
+    m = cm.kernel_map(key, key, 3, 1, region)
+    nbr, pin, pout = cm.export_map(m)
+    nbr = nbr.long()
+    assert int((nbr >= 0).sum()) == m.M
+    centre = [k for k in range(27) if m.mirror[k] == k][0]
+    assert torch.equal(nbr[centre], torch.arange(n, device=nbr.device))
+    for k in (0, 5, 13, 20, 26):  # symmetry: j -> i through k  <=>  i -> j through mirror(k)
+      valid = nbr[k] >= 0
+      i = nbr[k][valid]
+      j = torch.nonzero(valid).squeeze(1)
+      assert torch.equal(nbr[m.mirror[k]][i], j)
+    # coordinates really differ by the offset
+    offs = torch.as_tensor(np.array(ME.KernelGenerator(3, 1, 1, region_type=ME.RegionType(region), dimension=3).get_kernel()[1]))
+    cd = cm.get_coords(key).long()
+    k = 7
+    valid = nbr[k] >= 0
+    d = cd[nbr[k][valid]][:, 1:] - cd[valid][:, 1:]
+    assert (d.cpu() == offs[k].long()).all() and (cd[nbr[k][valid]][:, 0] == cd[valid][:, 0]).all()
+  sizes = [n]
+  for lvl in range(4):
+    ck = cm.stride(key, 2)
+    m2 = cm.kernel_map(key, ck, 2, 2, 0)
+    child, pin, pout = cm.export_map(m2)
+    assert m2.M == cm.size(key) and int((child >= 0).sum()) == m2.M
+    assert torch.equal(torch.sort(child[child >= 0])[0].long(), torch.arange(cm.size(key), device=child.device))
+    cf, cc = cm.get_coords(key).long(), cm.get_coords(ck).long()
+    ts2 = ck.tensor_stride
+    par = torch.div(cf[pin.long()][:, 1:], ts2, rounding_mode="floor") * ts2
+    assert torch.equal(par, cc[pout.long()][:, 1:])
+    assert len(torch.unique(cc, dim=0)) == len(cc)
+    sizes.append(cm.size(ck))
+    key = ck
+  assert sizes == sorted(sizes, reverse=True)
+
+
+@pytest.mark.parametrize("kind,cin,cout", [("k3", 96, 96), ("k3", 128, 96), ("down", 32, 32), ("up", 96, 96), ("1x1", 96, 32)])
+def test_full_size_conv_linearity_and_adjointness(ME, full_batch, kind, cin, cout):
+  """conv(a x + b y) = a conv(x) + b conv(y);  <conv(x), g> = <x, bwd_data(g)> = <W, bwd_weight(x, g)>."""
+  from pointcontrast_amd import functional as PF
+  C = full_batch["sinput1_C"]
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  torch.manual_seed(1)
+  if kind == "k3":
+    m, tr, n_in, n_out, K = cm.kernel_map(key, key, 3, 1, 3), False, len(C), len(C), 27
+  elif kind == "down":
+    ck = cm.stride(key, 2)
+    m = cm.kernel_map(key, ck, 2, 2, 0)
+    tr, n_in, n_out, K = False, m.n_in, m.n_out, 8
+  elif kind == "up":
+    ck = cm.stride(key, 2)
+    m = cm.kernel_map(key, ck, 2, 2, 0)
+    tr, n_in, n_out, K = True, m.n_out, m.n_in, 8
+  else:
+    m, tr, n_in, n_out, K = None, False, len(C), len(C), 1
+  W = (torch.randn((K, cin, cout) if K > 1 else (cin, cout), device=DEV) / (cin * K) ** 0.5).requires_grad_(True)
+  x = torch.randn(n_in, cin, device=DEV, requires_grad=True)
+  y = torch.randn(n_in, cin, device=DEV)
+  f = lambda t: PF.SparseConvFunction.apply(t, W, None, m, tr, n_out, cm)
+  ox = f(x)
+  lin = f(1.5 * x.detach() - 0.5 * y)
+  assert_close(lin, 1.5 * ox.detach() - 0.5 * f(y).detach(), 1e-5, "linearity")
+  g = torch.randn(n_out, cout, device=DEV)
+  ox.backward(g)
+  lhs = (ox.detach().double() * g.double()).sum()
+  assert abs(float((x.detach().double() * x.grad.double()).sum() - lhs)) <= 1e-5 * abs(float(lhs)) + 1e-3
+  assert abs(float((W.detach().double() * W.grad.double()).sum() - lhs)) <= 1e-5 * abs(float(lhs)) + 1e-3

@@ -1,0 +1,107 @@
+"""CPU-side tests: C-ABI library loads and exports every symbol of include/pcmi.h, host-only
+entry points, configuration / sampler / batch-contract logic, pair selection vs the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+  hdr = open(os.path.join(ROOT, "include", "pcmi.h")).read()
+  hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+  declared = sorted(set(re.findall(r"\b(pcmi_[a-z0-9_]+)\s*\(", hdr)))
+  assert len(declared) >= 40
+  lib = ctypes.CDLL(built_lib)
+  missing = [s for s in declared if not hasattr(lib, s)]
+  assert not missing, missing
+  from pointcontrast_amd import _lib
+  assert sorted(_lib.PROTOTYPES) == declared, set(declared) ^ set(_lib.PROTOTYPES)
+  assert _lib.version() == 100
+
+
+def test_kernel_offsets_host_entry_matches_oracle(built_lib):
+  from oracle import sparse_ref as sr
+  from pointcontrast_amd._lib import lib, check
+  for ks, region in ((3, 0), (3, 3), (2, 0), (1, 0)):
+    buf = (ctypes.c_int32 * 81)()
+    K = ctypes.c_int()
+    check(lib.pcmi_kernel_offsets(ks, region, buf, ctypes.byref(K)))
+    got = np.ctypeslib.as_array(buf)[:K.value * 3].reshape(-1, 3)
+    assert (got == sr.region_offsets(ks, region)).all(), (ks, region)
+
+
+def test_errors_are_reported_not_swallowed(built_lib):
+  from pointcontrast_amd._lib import lib, check, PcmiError
+  buf = (ctypes.c_int32 * 81)()
+  K = ctypes.c_int()
+  with pytest.raises(PcmiError, match="not on the hot path"):
+    check(lib.pcmi_kernel_offsets(5, 0, buf, ctypes.byref(K)))
+
+
+def test_ops_refuse_cpu_tensors(built_lib):
+  """No CPU fallback: the product path must fail loudly without a device."""
+  from pointcontrast_amd import functional as PF
+  from pointcontrast_amd._lib import PcmiError
+  with pytest.raises(PcmiError, match="no CPU path"):
+    PF.ReLUFunction.apply(torch.zeros(4, 4))
+  with pytest.raises(PcmiError, match="no CPU path"):
+    PF.NCELossFunction.apply(torch.zeros(4, 32), torch.zeros(4, 32), 0.4)
+
+
+def test_config_defaults_and_overrides():
+  from pointcontrast_amd.lib.config import get_config
+  c = get_config(["misc.nceT=0.4", "trainer.trainer=PointNCELossTrainer", "opt.lr=0.05", "data.voxel_size=0.01"])
+  assert c.misc.nceT == 0.4 and c.opt.lr == 0.05 and c.trainer.trainer == "PointNCELossTrainer"
+  assert c.opt.momentum == 0.8 and c.opt.weight_decay == 1e-4 and c.opt.bn_momentum == 0.05  # defaults.yaml:43-53
+  assert c.trainer.num_pos_per_batch == 1024 and c.trainer.num_hn_samples_per_batch == 256 and c.misc.npos == 4096
+
+
+def test_samplers():
+  from pointcontrast_amd.lib.data_sampler import DistributedInfSampler, InfSampler
+  torch.manual_seed(0)
+  s = InfSampler(list(range(5)), shuffle=False)
+  assert [next(s) for _ in range(7)] == [4, 3, 2, 1, 0, 4, 3]
+  torch.manual_seed(0)
+  a = DistributedInfSampler(list(range(10)), num_replicas=2, rank=0)
+  torch.manual_seed(0)
+  b = DistributedInfSampler(list(range(10)), num_replicas=2, rank=1)
+  xa, xb = [next(a) for _ in range(5)], [next(b) for _ in range(5)]
+  assert sorted(xa + xb) == list(range(10))  # ranks stride one shared permutation
+
+
+def test_synthetic_batch_contract():
+  from pointcontrast_amd.lib.ddp_data_loaders import default_collate_pair_fn
+  from pointcontrast_amd.lib import synthetic
+  rng = np.random.RandomState(3)
+  items = [synthetic.make_pair_item(rng, 0.025, crop=0.5) for _ in range(2)]
+  b = default_collate_pair_fn(items)
+  C0, F0, corr = b["sinput0_C"], b["sinput0_F"], b["correspondences"]
+  assert C0.dtype == torch.int32 and F0.dtype == torch.float32 and corr.dtype == torch.int32
+  assert C0.shape[1] == 4 and F0.shape == (C0.shape[0], 3)
+  assert set(C0[:, 0].tolist()) == {0, 1}  # batch index FIRST
+  assert len(np.unique(C0.numpy(), axis=0)) == len(C0)  # unique voxels
+  assert (np.diff(corr[:, 0].numpy()) >= 0).all()  # sorted by query row (needed by the NCE selection)
+  assert corr[:, 0].max() < C0.shape[0] and corr[:, 1].max() < b["sinput1_C"].shape[0]
+  n0 = b["len_batch"][0][0]
+  second = corr[corr[:, 0] >= n0]
+  assert (second[:, 1] >= b["len_batch"][0][1]).all()  # offsets applied to both columns
+
+
+def test_pair_selection_matches_oracle():
+  from oracle import loss_ref as lr
+  from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer, _hash
+  rng = np.random.RandomState(0)
+  q = np.sort(rng.randint(0, 300, 2000))
+  pp = np.stack([q, rng.randint(0, 500, 2000)], 1).astype(np.int32)
+  nq = len(np.unique(q))
+  u = torch.rand(nq)
+  si = rng.choice(nq, 100, replace=False)
+  a = PointNCELossTrainer.select_pairs(torch.from_numpy(pp), 100, dict(uniform=u, sampled_inds=si))
+  b = lr.nce_select_pairs(pp, u, si)
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+  assert (_hash(pp.astype(np.int64), 1000) == lr.hash_pairs(pp[:, 0], pp[:, 1], 1000)).all()
