@@ -365,6 +365,17 @@ class MinkowskiBatchNorm(nn.Module):
     super().__init__()
     assert affine and track_running_stats
     self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
+    # num_batches_tracked only matters for momentum=None; count on the host and fold it into the
+    # buffer when a state_dict is taken instead of launching a 1-element kernel per forward
+    self._untracked = 0
+    self.register_state_dict_pre_hook(MinkowskiBatchNorm._flush_tracked)
+
+  @staticmethod
+  def _flush_tracked(module, prefix, keep_vars):
+    if module._untracked:
+      with torch.no_grad():
+        module.bn.num_batches_tracked += module._untracked
+      module._untracked = 0
 
   def forward(self, x, residual=None, relu=False):
     """``residual`` / ``relu`` select the fused epilogue (the unfused call is forward(x))."""
@@ -373,8 +384,7 @@ class MinkowskiBatchNorm(nn.Module):
     if self.training:
       y = PF.BatchNormFunction.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                      res, relu)
-      with torch.no_grad():
-        bn.num_batches_tracked += 1
+      self._untracked += 1
     else:
       y = PF.batch_norm_eval(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, res, relu)
     return SparseTensor(y, coords_key=x.coords_key, coords_manager=x.coords_man)
