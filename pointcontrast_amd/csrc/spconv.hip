@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
       s_orow[t] = p < pend ? a.pair_dst[p] : -1;
     }
     if (t == 0) {
-      s_klist[0] = k_single;
+      s_klist[0] = 0;  // slot of s_idx; the weight slice comes from k_single
       s_nk = 1;
     }
   } else {

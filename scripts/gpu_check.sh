@@ -1,18 +1,25 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): GPU parity tests, smoke, a short bench, and a rocprofv3 kernel-trace
-# of the bench.  Everything is logged under gpurun_out/ (merged back by gpurun).
+# Runs on the GPU box (via gpurun): GPU parity tests (one process per group, so a device fault in
+# one group cannot hide the others), smoke, a short bench, and a rocprofv3 kernel-trace of the
+# bench.  Everything is logged under gpurun_out/ (merged back by gpurun).
 set -u
+ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 STEPS=${STEPS:-10}
 WARM=${WARM:-3}
-echo "== rocminfo" > gpurun_out/env.log
-(rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2) >> gpurun_out/env.log 2>&1
+(rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2) > gpurun_out/env.log 2>&1
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { echo "build failed"; tail -5 gpurun_out/build.log; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
-  echo "pytest exit: $?" >> gpurun_out/pytest_gpu.log
-  tail -5 gpurun_out/pytest_gpu.log
+  : > gpurun_out/pytest_gpu.log
+  GROUPS_DEFAULT="maps_ single_voxel spconv_parity stem_conv spconv_golden batchnorm bn_eval nce_parity gather_scatter pdist hardest_loss sgd_step network_features trainer_iteration full_size"
+  for grp in ${TEST_GROUPS:-$GROUPS_DEFAULT}; do
+    echo "=== group $grp" >> gpurun_out/pytest_gpu.log
+    timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "$grp" >> gpurun_out/pytest_gpu.log 2>&1
+    echo "=== group $grp exit: $?" >> gpurun_out/pytest_gpu.log
+  done
+  grep -E "^=== group .* exit|passed|failed|error" gpurun_out/pytest_gpu.log | tail -40
 fi
 if [ "${SKIP_SMOKE:-0}" != "1" ]; then
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
@@ -30,7 +37,6 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   echo "prof exit: $?" >> "$GRAFT_REPO_ROOT/gpurun_out/prof.log"
   cd "$GRAFT_REPO_ROOT"
   find gpurun_out/prof -name "*kernel_stats*" | head
-  # keep the merged payload small: drop the raw trace, keep the stats
   find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
 fi
 echo done
