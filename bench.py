@@ -161,7 +161,9 @@ def cpu_baseline(batch_size_sample=1):
   synthetic pairs: one untimed + one timed iteration, all host cores."""
   import torch
   from oracle import loss_ref as lr, model_ref as mr, sparse_ref as sr
-  cores = os.cpu_count() or 1
+  # torch-CPU index_select / index_add_ / mm stop scaling long before a 256-thread host is full
+  # (and oversubscription makes them slower), so the baseline uses at most 32 threads
+  cores = min(os.cpu_count() or 1, int(os.environ.get("PCMI_CPU_BASELINE_THREADS", "32")))
   torch.set_num_threads(cores)
   b = get_batch(seed=0, batch_size=batch_size_sample, voxel_size=0.025)
   torch.manual_seed(0)
@@ -187,6 +189,26 @@ def cpu_baseline(batch_size_sample=1):
           "kind": "port",
           "sample": "%d pair(s) (N0=%d, N1=%d voxels), full oracle iteration (2 fwd + NCE + bwd + SGD), 1 untimed + 1 timed"
                     % (batch_size_sample, b["sinput0_C"].shape[0], b["sinput1_C"].shape[0])}
+
+
+def run_cpu_baseline_bounded(limit_s=240):
+  """Runs cpu_baseline() in a child process so that a slow host cannot stall the bench line."""
+  import subprocess
+  code = "import json, bench; print('CPUBASE' + json.dumps(bench.cpu_baseline(1)))"
+  try:
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=limit_s)
+    for line in r.stdout.splitlines():
+      if line.startswith("CPUBASE"):
+        return json.loads(line[len("CPUBASE"):])
+    return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "kind": "port",
+            "sample": "cpu baseline failed: " + (r.stderr or "")[-200:]}
+  except subprocess.TimeoutExpired:
+    return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "kind": "port",
+            "sample": "1 pair did not finish within %d s on this host" % limit_s}
+
+
+def log(msg):
+  print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
 def main():
@@ -233,6 +255,7 @@ def main():
   it = iter(loader)
   timers = [AverageMeter(), Timer(), Timer()]
 
+  log("warmup")
   for _ in range(args.warmup):
     res = trainer._train_iter(it, timers)
   torch.cuda.synchronize()
@@ -274,13 +297,15 @@ def main():
         f.write("layer\tK\tcin\tcout\tpairs\tn_out\tflops\talgo_bytes\n")
         for r in rows:
           f.write("\t".join(str(v) for v in r) + "\n")
+    log("timed region done: %.2f ms/step" % (elapsed / args.steps * 1e3))
     if not args.no_roofline:
       dom, kernels = kernel_rooflines(batch, device)
+      log("rooflines done")
       out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                          "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "ms": dom["ms"]}
       out["kernels"] = kernels
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(1)
+      out["cpu_baseline"] = run_cpu_baseline_bounded()
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()

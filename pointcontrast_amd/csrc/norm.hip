@@ -97,14 +97,19 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
   }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblocks, int64_t n, int c,
-                                      int rows_per_block, float eps, float momentum,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// One 64-lane wave per channel: lanes stride over the per-block partials, then the (n, mean, M2)
+// triples are merged across lanes with Chan's update (associative, fixed order -> deterministic).
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part, int nblocks, int64_t n, int c,
+                                                             int rows_per_block, float eps, float momentum,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var,
+                                                             float* __restrict__ save_mean,
+                                                             float* __restrict__ save_invstd) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
+  for (int b = lane; b < nblocks; b += 64) {
     const int64_t r0 = (int64_t)b * rows_per_block;
     const float nb = (float)(min(r0 + (int64_t)rows_per_block, n) - r0);
     const float mb = part[(int64_t)b * 2 * c + ch], m2b = part[(int64_t)b * 2 * c + c + ch];
@@ -114,6 +119,20 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblock
     m2 += m2b + delta * delta * (cnt * nb / tot);
     cnt = tot;
   }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float ocnt = __shfl_xor(cnt, d, 64), omean = __shfl_xor(mean, d, 64), om2 = __shfl_xor(m2, d, 64);
+    const float tot = cnt + ocnt;
+    if (tot > 0.f) {
+      // symmetric form so that both partners compute bit-identical results
+      const float delta = omean - mean;
+      const float nmean = (cnt * mean + ocnt * omean) / tot;
+      m2 = m2 + om2 + delta * delta * (cnt * ocnt / tot);
+      mean = nmean;
+      cnt = tot;
+    }
+  }
+  if (lane != 0) return;
   const float var = m2 / cnt;
   save_mean[ch] = mean;
   save_invstd[ch] = 1.0f / sqrtf(var + eps);
@@ -124,17 +143,25 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ part, int nblock
   }
 }
 
-__global__ void colsum2_final_kernel(const float* __restrict__ part, int nblocks, int c,
-                                     float* __restrict__ out_a, float* __restrict__ out_b) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                            float* __restrict__ out_a, float* __restrict__ out_b) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
   float a = 0.f, b = 0.f;
-  for (int q = 0; q < nblocks; ++q) {
+  for (int q = lane; q < nblocks; q += 64) {
     a += part[(int64_t)q * 2 * c + ch];
     b += part[(int64_t)q * 2 * c + c + ch];
   }
-  out_a[ch] = a;
-  out_b[ch] = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    a += __shfl_xor(a, d, 64);
+    b += __shfl_xor(b, d, 64);
+  }
+  if (lane == 0) {
+    out_a[ch] = a;
+    out_b[ch] = b;
+  }
 }
 
 // y = relu?( (x - mean) * (invstd * gamma) + beta (+ residual) )
@@ -304,7 +331,7 @@ int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const floa
   colreduce_partial_kernel<0><<<g.nblocks, 256, 0, st>>>(x, x_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, n, g.c4, g.rp,
                                                         g.rows_per_block, part);
   PCMI_LAUNCH_CHECK();
-  bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 64)), 64, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
+  bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
                                                                        running_mean, running_var, save_mean, save_invstd);
   PCMI_LAUNCH_CHECK();
   bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
@@ -348,7 +375,7 @@ int pcmi_bn_bwd(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
                                                         g.c4, g.rp, g.rows_per_block, part);
   PCMI_LAUNCH_CHECK();
-  colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 64)), 64, 0, st>>>(part, g.nblocks, c, dbeta, dgamma);
+  colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma);
   PCMI_LAUNCH_CHECK();
   bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
                                                             save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld);

@@ -33,10 +33,10 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
 fi
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > "$GRAFT_REPO_ROOT/gpurun_out/prof.log" 2>&1
   echo "prof exit: $?" >> "$GRAFT_REPO_ROOT/gpurun_out/prof.log"
   cd "$GRAFT_REPO_ROOT"
   find gpurun_out/prof -name "*kernel_stats*" | head
-  find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
+  find gpurun_out/prof -name "*kernel_trace*" -size +8M -delete
 fi
 echo done
