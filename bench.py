@@ -220,6 +220,7 @@ def main():
   ap.add_argument("--voxel", type=float, default=0.025)
   ap.add_argument("--loss", choices=["nce", "hardest"], default="nce")
   ap.add_argument("--model", default="Res16UNet34C")
+  ap.add_argument("--engine", choices=["native", "autograd"], default="native")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
   ap.add_argument("--layer-table", default=None, help="write the per-layer work table to this path")
@@ -245,7 +246,8 @@ def main():
   from pointcontrast_amd.lib import ddp_trainer
   from pointcontrast_amd.lib.timer import AverageMeter, Timer
   cfg = get_config(["net.model=%s" % args.model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1",
-                    "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world)])
+                    "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world),
+                    "misc.engine=%s" % args.engine])
   batch = get_batch(seed=rank, batch_size=args.batch, voxel_size=args.voxel)
   loader = FixedBatchLoader([batch], batch_size=args.batch)
   torch.manual_seed(0)
@@ -278,7 +280,12 @@ def main():
 
   if rank == 0:
     n0, n1 = batch["sinput0_C"].shape[0], batch["sinput1_C"].shape[0]
-    flops, byts, rows = conv_work(trainer.model)  # last forward = cloud 1
+    if args.engine == "native":  # per-layer pair counts are recorded by the module path: one untimed forward
+      import pointcontrast_amd.minkowski as ME
+      with torch.no_grad():
+        trainer.model(ME.SparseTensor(batch["sinput1_F"], coords=batch["sinput1_C"]).to(device))
+      torch.cuda.synchronize()
+    flops, byts, rows = conv_work(trainer.model)  # cloud 1
     out = {
         "metric": "scene-pairs/sec, ScanNet 2.5cm Res16UNet34C PointInfoNCE" if args.loss == "nce" else
                   "scene-pairs/sec, ScanNet 2.5cm Res16UNet34C HardestContrastive",
@@ -289,7 +296,7 @@ def main():
         "config": {"workload": "BASELINE configs[%d]: %s, %s loss, voxel %.3g m, %d pairs/GPU, %d+%d active voxels per "
                                "forward pair on rank 0, npos 4096, T 0.4, SGD(lr 0.1, mom 0.8, wd 1e-4)"
                                % (1 if args.loss == "nce" else 2, args.model, args.loss, args.voxel, args.batch, n0, n1),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": round(loss_val, 5),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine, "final_loss": round(loss_val, 5),
                    "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3)},
     }
     if args.layer_table:

@@ -255,6 +255,54 @@ size_t pcmi_hardest_workspace_bytes(int64_t p);
 int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum,
                   float weight_decay, float grad_scale, pcmi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Network executor -- the reference drives the 63 convs / 62 BNs of Res16UNet34C from Python
+ * (pc/model/res16unet.py:206-268, autograd for the backward).  Here a model is lowered ONCE into
+ * a static program (tensors + ops, built by tracing the Python module tree) and a whole forward
+ * or backward is ONE call that enqueues every kernel from C++: no per-layer host overhead,
+ * activations in a per-pass arena, concatenations as column slices of a shared buffer
+ * (zero copy), gradients accumulated straight into the flat gradient buffer.
+ *   tensor: (level, channels) rows = voxels of that level (tensor stride 2^level); parent >= 0
+ *           makes it the column slice [col_off, col_off + channels) of tensor `parent`.
+ *   op    : CONV (MinkowskiConvolution / Transpose), BN (+ residual, + ReLU), L2NORM.
+ * The training step of the reference needs two passes per iteration (one per point cloud,
+ * pc/lib/ddp_trainer.py:392-398): activations of pass p stay valid until pcmi_net_backward(p).
+ * ------------------------------------------------------------------------------------------ */
+#define PCMI_OP_CONV 0
+#define PCMI_OP_BN 1
+#define PCMI_OP_L2NORM 2
+
+typedef struct pcmi_net pcmi_net_t;
+typedef struct pcmi_net_tensor {
+  int32_t level, channels, parent, col_off;
+} pcmi_net_tensor_t;
+typedef struct pcmi_net_op {
+  int32_t type, in, in2, out;   /* tensor ids; in2 = residual input of a BN or -1 */
+  int32_t cin, cout, kernel_size, stride, region, transpose, relu, has_bias;
+  int64_t w_off, b_off;         /* flat-parameter offsets: conv kernel / bias, BN gamma / beta */
+  float* running_mean;          /* BN buffers (device pointers; not part of the flat parameters) */
+  float* running_var;
+  float momentum, eps;
+} pcmi_net_op_t;
+/* Called from pcmi_net_backward as soon as every gradient of parameter range `bucket` is final. */
+typedef void (*pcmi_ready_fn)(void* ctx, int bucket);
+
+int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_net_op_t* ops,
+                    int n_ops, int input_tensor, int output_tensor, int n_passes, pcmi_net_t** out);
+int pcmi_net_destroy(pcmi_net_t* net);
+/* in_feats [n_rows, in_ld] and out_feats [n_rows, out_ld] are caller memory; coords must hold
+ * key 0 with n_rows rows.  May sync the first times (arena growth, coordinate planning). */
+int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const float* in_feats,
+                     int64_t in_ld, int64_t n_rows, const float* params, int training,
+                     float* out_feats, int64_t out_ld, pcmi_stream_t stream);
+/* d_out: gradient w.r.t. out_feats.  Parameter gradients are ACCUMULATED into grads (flat, same
+ * layout as params; the caller zero-fills it once per iteration).  bucket_lo_host: ascending
+ * flat offsets splitting the parameters into n_buckets ranges (may be NULL / 0 with ready). */
+int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_ld,
+                      const float* params, float* grads, const int64_t* bucket_lo_host,
+                      int n_buckets, pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream);
+int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

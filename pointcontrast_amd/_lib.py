@@ -37,6 +37,23 @@ class KMap(C.Structure):
 
 _KP = C.POINTER(KMap)
 
+
+class NetTensor(C.Structure):
+  """struct pcmi_net_tensor."""
+  _fields_ = [("level", c_i32), ("channels", c_i32), ("parent", c_i32), ("col_off", c_i32)]
+
+
+class NetOp(C.Structure):
+  """struct pcmi_net_op."""
+  _fields_ = [("type", c_i32), ("in_", c_i32), ("in2", c_i32), ("out", c_i32),
+              ("cin", c_i32), ("cout", c_i32), ("kernel_size", c_i32), ("stride", c_i32), ("region", c_i32),
+              ("transpose", c_i32), ("relu", c_i32), ("has_bias", c_i32),
+              ("w_off", c_i64), ("b_off", c_i64), ("running_mean", c_vp), ("running_var", c_vp),
+              ("momentum", c_f32), ("eps", c_f32)]
+
+
+READY_FN = C.CFUNCTYPE(None, c_vp, C.c_int)
+
 # name -> (restype, argtypes); every symbol of include/pcmi.h
 PROTOTYPES = {
     "pcmi_version": (C.c_int, []),
@@ -89,6 +106,13 @@ PROTOTYPES = {
     "pcmi_hardest_loss_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pcmi_sgd_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "pcmi_net_create": (C.c_int, [C.POINTER(NetTensor), C.c_int, C.POINTER(NetOp), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(c_vp)]),
+    "pcmi_net_destroy": (C.c_int, [c_vp]),
+    "pcmi_net_forward": (C.c_int, [c_vp, C.c_int, c_vp, c_vp, c_i64, c_i64, c_vp, C.c_int, c_vp, c_i64, c_vp]),
+    "pcmi_net_backward": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, c_vp, c_vp, C.POINTER(c_i64), C.c_int, READY_FN, c_vp,
+                                    c_vp]),
+    "pcmi_net_memory_bytes": (C.c_int, [c_vp, C.POINTER(c_sz)]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

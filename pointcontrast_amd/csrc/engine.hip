@@ -1,0 +1,384 @@
+// Network executor: a model lowered to a static program (tensors + ops) whose whole forward or
+// backward is enqueued from C++ in one call.  See include/pcmi.h ("Network executor").
+//
+// Memory: one activation arena per pass (every tensor of the forward stays resident until that
+// pass's backward: conv inputs, BN inputs and outputs are all needed again) and one gradient arena
+// shared by the passes (backward passes run one after the other).  A tensor with parent >= 0 is a
+// column slice of its parent's buffer, so a channel concatenation costs nothing: the producers
+// write their slice (leading dimension = parent width) and the consumer reads the parent.
+//
+// Gradient accumulation: walking the ops in reverse, the first contribution to a (buffer, column
+// range) overwrites, later ones accumulate inside the producing kernel's epilogue (no separate add
+// kernels, no zero-fill of activation gradients).  Which is which is decided once, at creation.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "internal.h"
+
+namespace pcmi {
+
+struct DevBuf {
+  char* p = nullptr;
+  size_t cap = 0;
+  // grows with 25 % head-room; the old block may still be in flight -> sync before freeing it
+  int reserve(size_t bytes, hipStream_t st) {
+    if (bytes <= cap) return PCMI_OK;
+    if (p) {
+      PCMI_HIP_CHECK(hipStreamSynchronize(st));
+      PCMI_HIP_CHECK(hipFree(p));
+      p = nullptr;
+      cap = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 4 + 4096, 1 << 20);
+    PCMI_HIP_CHECK(hipMalloc((void**)&p, want));
+    cap = want;
+    return PCMI_OK;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+struct OpPlan {
+  int acc_in = 0;   // gradient w.r.t. `in` accumulates (a previous op already wrote that range)
+  int acc_res = 0;  // gradient w.r.t. `in2` (BN residual) accumulates
+};
+
+struct PassState {
+  DevBuf act;
+  std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
+  std::vector<size_t> stat_off;    // per op: BN save_mean/save_invstd (2*C floats) or L2 norms
+  std::vector<pcmi_kmap_t> maps;   // per op
+  std::vector<char> has_map;
+  std::vector<int64_t> rows;       // per level
+  const float* in_feats = nullptr;
+  int64_t in_ld = 0;
+  float* out_feats = nullptr;
+  int64_t out_ld = 0;
+  pcmi_coords_t* coords = nullptr;
+  bool valid = false;
+};
+
+}  // namespace pcmi
+
+struct pcmi_net {
+  std::vector<pcmi_net_tensor_t> tensors;
+  std::vector<pcmi_net_op_t> ops;
+  std::vector<pcmi::OpPlan> plan;
+  int input_tensor = -1, output_tensor = -1, n_levels = 0;
+  std::vector<pcmi::PassState> passes;
+  pcmi::DevBuf grad;
+  std::vector<size_t> grad_off;
+  pcmi::DevBuf ws;
+  pcmi::DevBuf small;  // dgamma/dbeta scratch
+};
+
+namespace pcmi {
+
+static int root_of(const pcmi_net& n, int t) {
+  while (n.tensors[t].parent >= 0) t = n.tensors[t].parent;
+  return t;
+}
+static int col_of(const pcmi_net& n, int t) {
+  int c = 0;
+  while (n.tensors[t].parent >= 0) {
+    c += n.tensors[t].col_off;
+    t = n.tensors[t].parent;
+  }
+  return c;
+}
+
+struct View {
+  float* p;
+  int64_t ld;
+};
+
+static View act_view(const pcmi_net& n, const PassState& ps, int t) {
+  if (t == n.input_tensor) return {const_cast<float*>(ps.in_feats), ps.in_ld};
+  if (t == n.output_tensor) return {ps.out_feats, ps.out_ld};
+  const int r = root_of(n, t);
+  float* base = (float*)(ps.act.p + ps.tensor_off[r]);
+  return {base + col_of(n, t), (int64_t)n.tensors[r].channels};
+}
+
+static View grad_view(const pcmi_net& n, int t, const float* d_out, int64_t d_ld) {
+  if (t == n.output_tensor) return {const_cast<float*>(d_out), d_ld};
+  const int r = root_of(n, t);
+  float* base = (float*)(n.grad.p + n.grad_off[r]);
+  return {base + col_of(n, t), (int64_t)n.tensors[r].channels};
+}
+
+static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out, int64_t M) {
+  if (op.type == PCMI_OP_CONV) {
+    const int K = op.kernel_size * op.kernel_size * op.kernel_size;
+    return pcmi_spconv_workspace_bytes(n_in, n_out, op.cin, op.cout, K, M);
+  }
+  if (op.type == PCMI_OP_BN) return pcmi_bn_workspace_bytes(n_in, op.cout);
+  return 0;
+}
+
+}  // namespace pcmi
+
+using namespace pcmi;
+
+extern "C" {
+
+int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_net_op_t* ops, int n_ops,
+                    int input_tensor, int output_tensor, int n_passes, pcmi_net_t** out) {
+  PCMI_REQUIRE(tensors && ops && out && n_tensors > 0 && n_ops > 0 && n_passes > 0 && n_passes <= 8, PCMI_ERR_INVALID,
+               "net_create: bad argument");
+  PCMI_REQUIRE(input_tensor >= 0 && input_tensor < n_tensors && output_tensor >= 0 && output_tensor < n_tensors,
+               PCMI_ERR_INVALID, "net_create: bad input/output tensor id");
+  pcmi_net* n = new pcmi_net();
+  n->tensors.assign(tensors, tensors + n_tensors);
+  n->ops.assign(ops, ops + n_ops);
+  n->plan.resize(n_ops);
+  n->input_tensor = input_tensor;
+  n->output_tensor = output_tensor;
+  n->passes.resize(n_passes);
+  auto fail = [&](const char* msg, int i) {
+    set_error("net_create: %s (index %d)", msg, i);
+    delete n;
+    return PCMI_ERR_INVALID;
+  };
+  for (int t = 0; t < n_tensors; ++t) {
+    const auto& T = n->tensors[t];
+    if (T.level < 0 || T.level > 12 || T.channels <= 0) return fail("bad tensor", t);
+    if (T.parent >= 0) {
+      if (T.parent >= n_tensors || T.parent == t) return fail("bad parent", t);
+      const auto& P = n->tensors[T.parent];
+      if (P.level != T.level || T.col_off < 0 || T.col_off + T.channels > P.channels || T.col_off % 4 != 0)
+        return fail("slice does not fit its parent (or is not 16-byte aligned)", t);
+    }
+    n->n_levels = std::max(n->n_levels, T.level + 1);
+  }
+  if (n->tensors[input_tensor].parent >= 0 || n->tensors[output_tensor].parent >= 0)
+    return fail("the network input / output must be root tensors", input_tensor);
+  // decide overwrite vs accumulate for every gradient contribution, walking backward
+  std::vector<std::vector<char>> touched(n_tensors);
+  for (int t = 0; t < n_tensors; ++t)
+    if (n->tensors[t].parent < 0) touched[t].assign(n->tensors[t].channels, 0);
+  auto contribute = [&](int t, int* acc_flag) -> bool {
+    const int r = root_of(*n, t), c0 = col_of(*n, t), c1 = c0 + n->tensors[t].channels;
+    int cnt = 0;
+    for (int c = c0; c < c1; ++c) cnt += touched[r][c];
+    if (cnt != 0 && cnt != c1 - c0) return false;  // partially written range: not expressible
+    *acc_flag = cnt != 0;
+    for (int c = c0; c < c1; ++c) touched[r][c] = 1;
+    return true;
+  };
+  for (int i = n_ops - 1; i >= 0; --i) {
+    const auto& op = n->ops[i];
+    if (op.in < 0 || op.in >= n_tensors || op.out < 0 || op.out >= n_tensors || op.in2 >= n_tensors)
+      return fail("bad tensor id in op", i);
+    if (op.type == PCMI_OP_CONV) {
+      if (n->tensors[op.in].channels != op.cin || n->tensors[op.out].channels != op.cout) return fail("conv channels", i);
+      if (op.in != input_tensor && !contribute(op.in, &n->plan[i].acc_in)) return fail("mixed gradient coverage", i);
+    } else if (op.type == PCMI_OP_BN) {
+      if (n->tensors[op.in].channels != op.cout || n->tensors[op.out].channels != op.cout) return fail("bn channels", i);
+      if (op.in2 >= 0 && !contribute(op.in2, &n->plan[i].acc_res)) return fail("mixed gradient coverage", i);
+      if (!contribute(op.in, &n->plan[i].acc_in) || n->plan[i].acc_in) return fail("BN input must have a single consumer", i);
+    } else if (op.type == PCMI_OP_L2NORM) {
+      if (!contribute(op.in, &n->plan[i].acc_in) || n->plan[i].acc_in) return fail("L2NORM input must have a single consumer", i);
+    } else {
+      return fail("unknown op type", i);
+    }
+  }
+  *out = n;
+  return PCMI_OK;
+}
+
+int pcmi_net_destroy(pcmi_net_t* net) {
+  delete net;
+  return PCMI_OK;
+}
+
+int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
+  PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
+  size_t b = net->grad.cap + net->ws.cap + net->small.cap;
+  for (auto& p : net->passes) b += p.act.cap;
+  *bytes = b;
+  return PCMI_OK;
+}
+
+int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const float* in_feats, int64_t in_ld,
+                     int64_t n_rows, const float* params, int training, float* out_feats, int64_t out_ld,
+                     pcmi_stream_t stream) {
+  PCMI_REQUIRE(net && coords && in_feats && params && out_feats, PCMI_ERR_INVALID, "net_forward: null argument");
+  PCMI_REQUIRE(pass >= 0 && pass < (int)net->passes.size(), PCMI_ERR_INVALID, "net_forward: bad pass %d", pass);
+  hipStream_t st = as_stream(stream);
+  pcmi_net& n = *net;
+  PassState& ps = n.passes[pass];
+  ps.valid = false;
+  const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
+  // ---- level sizes (cache hits once the coordinate plan exists) ------------------------------------
+  std::vector<int> keys(n.n_levels, 0);
+  ps.rows.assign(n.n_levels, 0);
+  int64_t n0 = 0;
+  int rc = pcmi_coords_size(coords, 0, &n0, nullptr);
+  if (rc) return rc;
+  PCMI_REQUIRE(n0 == n_rows, PCMI_ERR_INVALID, "net_forward: %lld feature rows but %lld coordinates", (long long)n_rows,
+               (long long)n0);
+  ps.rows[0] = n0;
+  for (int l = 1; l < n.n_levels; ++l) {
+    rc = pcmi_coords_stride(coords, keys[l - 1], 2, &keys[l], &ps.rows[l], stream);
+    if (rc) return rc;
+  }
+  // ---- maps, arena layout, workspace --------------------------------------------------------------
+  ps.maps.resize(n_ops);
+  ps.has_map.assign(n_ops, 0);
+  size_t ws_need = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const auto& op = n.ops[i];
+    const int li = n.tensors[op.in].level, lo = n.tensors[op.out].level;
+    int64_t M = ps.rows[li];
+    if (op.type == PCMI_OP_CONV && op.kernel_size > 1) {
+      if (!op.transpose && op.stride == 1) {
+        PCMI_REQUIRE(li == lo, PCMI_ERR_INVALID, "net: op %d: stride-1 conv across levels", i);
+        rc = pcmi_kmap_get(coords, keys[li], keys[li], op.kernel_size, 1, op.region, &ps.maps[i], stream);
+      } else if (!op.transpose) {
+        PCMI_REQUIRE(lo == li + 1, PCMI_ERR_INVALID, "net: op %d: strided conv must go one level down", i);
+        rc = pcmi_kmap_get(coords, keys[li], keys[lo], op.kernel_size, op.stride, op.region, &ps.maps[i], stream);
+      } else {
+        PCMI_REQUIRE(lo == li - 1, PCMI_ERR_INVALID, "net: op %d: transposed conv must go one level up", i);
+        rc = pcmi_kmap_get(coords, keys[lo], keys[li], op.kernel_size, op.stride, op.region, &ps.maps[i], stream);
+      }
+      if (rc) return rc;
+      ps.has_map[i] = 1;
+      M = ps.maps[i].M;
+    }
+    ws_need = std::max(ws_need, op_workspace(op, ps.rows[li], ps.rows[lo], M));
+  }
+  ps.tensor_off.assign(n_t, 0);
+  size_t off = 0;
+  for (int t = 0; t < n_t; ++t) {
+    if (n.tensors[t].parent >= 0 || t == n.input_tensor || t == n.output_tensor) continue;
+    ps.tensor_off[t] = off;
+    off += align_up((size_t)ps.rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
+  }
+  ps.stat_off.assign(n_ops, 0);
+  for (int i = 0; i < n_ops; ++i) {
+    const auto& op = n.ops[i];
+    ps.stat_off[i] = off;
+    if (op.type == PCMI_OP_BN) off += align_up((size_t)2 * op.cout * sizeof(float), 256);
+    if (op.type == PCMI_OP_L2NORM) off += align_up((size_t)ps.rows[n.tensors[op.in].level] * sizeof(float), 256);
+  }
+  rc = ps.act.reserve(off, st);
+  if (rc) return rc;
+  rc = n.ws.reserve(ws_need + 256, st);
+  if (rc) return rc;
+  ps.in_feats = in_feats;
+  ps.in_ld = in_ld;
+  ps.out_feats = out_feats;
+  ps.out_ld = out_ld;
+  ps.coords = coords;
+  // ---- run --------------------------------------------------------------------------------------
+  for (int i = 0; i < n_ops; ++i) {
+    const auto& op = n.ops[i];
+    const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
+    const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
+    if (op.type == PCMI_OP_CONV) {
+      rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
+                          op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, n.ws.p, n.ws.cap,
+                          st);
+    } else if (op.type == PCMI_OP_BN) {
+      View r = {nullptr, 0};
+      if (op.in2 >= 0) r = act_view(n, ps, op.in2);
+      float* stats = (float*)(ps.act.p + ps.stat_off[i]);
+      if (training)
+        rc = pcmi_bn_fwd_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
+                               op.running_var, op.momentum, op.eps, r.p, r.ld, op.relu, y.p, y.ld, stats,
+                               stats + op.cout, n.ws.p, n.ws.cap, stream);
+      else
+        rc = pcmi_bn_fwd_eval(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
+                              op.running_var, op.eps, r.p, r.ld, op.relu, y.p, y.ld, stream);
+    } else {
+      rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), stream);
+    }
+    if (rc) return rc;
+  }
+  ps.valid = training != 0;
+  return PCMI_OK;
+}
+
+int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_ld, const float* params, float* grads,
+                      const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready, void* ready_ctx,
+                      pcmi_stream_t stream) {
+  PCMI_REQUIRE(net && d_out && params && grads, PCMI_ERR_INVALID, "net_backward: null argument");
+  PCMI_REQUIRE(pass >= 0 && pass < (int)net->passes.size() && net->passes[pass].valid, PCMI_ERR_INVALID,
+               "net_backward: pass %d has no training-mode forward to differentiate", pass);
+  hipStream_t st = as_stream(stream);
+  pcmi_net& n = *net;
+  PassState& ps = n.passes[pass];
+  const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
+  // gradient arena layout for this pass's row counts
+  n.grad_off.assign(n_t, 0);
+  size_t off = 0;
+  int max_c = 4;
+  for (int t = 0; t < n_t; ++t) {
+    max_c = std::max(max_c, n.tensors[t].channels);
+    if (n.tensors[t].parent >= 0 || t == n.input_tensor || t == n.output_tensor) continue;
+    n.grad_off[t] = off;
+    off += align_up((size_t)ps.rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
+  }
+  int rc = n.grad.reserve(off, st);
+  if (rc) return rc;
+  rc = n.small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
+  if (rc) return rc;
+  float* scratch_g = (float*)n.small.p;
+  // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
+  std::vector<int> bucket_last(std::max(n_buckets, 0), -1);
+  auto bucket_of = [&](int64_t offp) {
+    int b = 0;
+    for (int q = 0; q < n_buckets; ++q)
+      if (offp >= bucket_lo_host[q]) b = q;
+    return b;
+  };
+  if (ready && n_buckets > 0) {
+    for (int i = n_ops - 1; i >= 0; --i) {
+      const auto& op = n.ops[i];
+      if (op.type == PCMI_OP_L2NORM) continue;
+      bucket_last[bucket_of(op.w_off)] = i;
+      if (op.type == PCMI_OP_BN || op.has_bias) bucket_last[bucket_of(op.b_off)] = i;
+    }
+  }
+  for (int i = n_ops - 1; i >= 0; --i) {
+    const auto& op = n.ops[i];
+    const OpPlan& pl = n.plan[i];
+    const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
+    const View dy = grad_view(n, op.out, d_out, d_ld);
+    const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
+    if (op.type == PCMI_OP_CONV) {
+      const pcmi_kmap_t* map = ps.has_map[i] ? &ps.maps[i] : nullptr;
+      if (op.in != n.input_tensor) {
+        const View dx = grad_view(n, op.in, d_out, d_ld);
+        rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
+                                  n_in, pl.acc_in, n.ws.p, n.ws.cap, st);
+        if (rc) return rc;
+      }
+      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
+                                  grads + op.w_off, op.has_bias ? grads + op.b_off : nullptr, 1, n.ws.p, n.ws.cap, st);
+    } else if (op.type == PCMI_OP_BN) {
+      const View dx = grad_view(n, op.in, d_out, d_ld);
+      View dr = {nullptr, 0};
+      if (op.in2 >= 0) dr = grad_view(n, op.in2, d_out, d_ld);
+      const float* stats = (const float*)(ps.act.p + ps.stat_off[i]);
+      rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats,
+                       stats + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, scratch_g + op.cout,
+                       grads + op.w_off, grads + op.b_off, n.ws.p, n.ws.cap, st);
+    } else {
+      const View dx = grad_view(n, op.in, d_out, d_ld);
+      rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps.act.p + ps.stat_off[i]), n_in, op.cout, dx.p, dx.ld,
+                           stream);
+    }
+    if (rc) return rc;
+    if (ready)
+      for (int b = 0; b < n_buckets; ++b)
+        if (bucket_last[b] == i) ready(ready_ctx, b);
+  }
+  ps.valid = false;
+  return PCMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+// Cross-file internal entry points (same semantics as the C ABI, plus accumulate flags).
+#pragma once
+#include "common.h"
+
+namespace pcmi {
+
+int spconv_forward(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
+                   const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
+                   int64_t n_out, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int spconv_backward_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
+                         const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
+                         int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                           int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
+                           float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
+                int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,
+                float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace pcmi

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ part, int nblocks, int c,
-                                                            float* __restrict__ out_a, float* __restrict__ out_b) {
+                                                            float* __restrict__ out_a, float* __restrict__ out_b,
+                                                            float* __restrict__ acc_a, float* __restrict__ acc_b) {
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restr
   if (lane == 0) {
     out_a[ch] = a;
     out_b[ch] = b;
+    if (acc_a) {  // parameter gradients accumulated into a second (flat) buffer
+      acc_a[ch] += a;
+      acc_b[ch] += b;
+    }
   }
 }
 
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ ymask, int64_t y_ld, int64_t n, int c4, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ sum_g,
     const float* __restrict__ sum_gx, float* __restrict__ dx, int64_t dx_ld, float* __restrict__ dres,
-    int64_t dres_ld) {
+    int64_t dres_ld, int dres_accumulate) {
   const int64_t total = n * c4;
   const float inv_n = 1.0f / (float)n;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -232,7 +237,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
     o.w = ga.w * is.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * is.w * sx.w * inv_n);
     *reinterpret_cast<float4*>(dx + r * dx_ld + col * 4) = o;
-    if (dres) *reinterpret_cast<float4*>(dres + r * dres_ld + col * 4) = g;
+    if (dres) {
+      float4* dp = reinterpret_cast<float4*>(dres + r * dres_ld + col * 4);
+      if (dres_accumulate) {
+        const float4 o = *dp;
+        g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+      }
+      *dp = g;
+    }
   }
 }
 
@@ -355,10 +367,14 @@ int pcmi_bn_fwd_eval(const float* x, int64_t x_ld, int64_t n, int c, const float
   return PCMI_OK;
 }
 
-int pcmi_bn_bwd(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
+}  // extern "C"
+
+namespace pcmi {
+// dgamma / dbeta: this call's sums (scratch, overwritten); acc_dgamma / acc_dbeta (nullable): += the same sums.
+int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
                 int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
-                int64_t dx_ld, float* dres, int64_t dres_ld, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                pcmi_stream_t stream) {
+                int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,
+                float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st) {
   int rc = check_rows("bn_bwd(dy)", dy, dy_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_bwd(x)", x, x_ld, c);
@@ -369,18 +385,29 @@ int pcmi_bn_bwd(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   if (dres && (rc = check_rows("bn_bwd(dres)", dres, dres_ld, c))) return rc;
   PCMI_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && n > 0, PCMI_ERR_INVALID, "bn_bwd: bad argument");
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_bwd: workspace too small");
-  hipStream_t st = as_stream(stream);
   const RedGeom g = red_geom(n, c);
   float* part = (float*)ws;
   colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
                                                         g.c4, g.rp, g.rows_per_block, part);
   PCMI_LAUNCH_CHECK();
-  colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma);
+  colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
   PCMI_LAUNCH_CHECK();
   bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
-                                                            save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld);
+                                                            save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld, dres_accumulate);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
+}
+
+}  // namespace pcmi
+
+extern "C" {
+
+int pcmi_bn_bwd(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
+                int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
+                int64_t dx_ld, float* dres, int64_t dres_ld, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                pcmi_stream_t stream) {
+  return bn_backward(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, c, gamma, save_mean, save_invstd, dx, dx_ld, dres, dres_ld, 0,
+                     dgamma, dbeta, nullptr, nullptr, ws, ws_bytes, as_stream(stream));
 }
 
 int pcmi_relu_fwd(const float* x, int64_t x_ld, int64_t n, int c, float* y, int64_t y_ld, pcmi_stream_t stream) {

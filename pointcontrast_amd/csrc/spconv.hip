@@ -58,6 +58,7 @@ struct ConvArgs {
   int64_t split_stride;  // floats between partial buffers
   int ksplit;            // offsets are divided into ksplit contiguous ranges over blockIdx.z
   const float* bias;     // nullable, only when ksplit == 1
+  int accumulate;        // out += result instead of out = result (only when ksplit == 1)
 };
 
 template <int NT, int RW, bool WT, bool PAIR>
@@ -291,8 +292,13 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
       const int32_t orow = s_orow[rg * 32 + i];
       if (orow >= 0) {
         float* op = outp + (int64_t)orow * a.out_ld + n0 + r;
+        if (a.accumulate) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[nt][j] + bv[nt];
+          for (int nt = 0; nt < NT; ++nt) op[nt * 32] += acc[nt][j] + bv[nt];
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) op[nt * 32] = acc[nt][j] + bv[nt];
+        }
       }
     }
   }
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
 // out[row, n] = sum_s partial[s][row, n] (+ bias)
 __global__ void split_reduce_kernel(const float* __restrict__ part, int64_t split_stride, int ksplit,
                                     int64_t n_rows, int N, const float* __restrict__ bias,
-                                    float* __restrict__ out, int64_t out_ld) {
+                                    float* __restrict__ out, int64_t out_ld, int accumulate) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
   const int n4 = N / 4;
   if (idx >= n_rows * n4) return;
@@ -321,7 +327,15 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int64_t spli
     s.z += bias[c + 2];
     s.w += bias[c + 3];
   }
-  *reinterpret_cast<float4*>(out + row * out_ld + c) = s;
+  float4* dst = reinterpret_cast<float4*>(out + row * out_ld + c);
+  if (accumulate) {
+    const float4 o = *dst;
+    s.x += o.x;
+    s.y += o.y;
+    s.z += o.z;
+    s.w += o.w;
+  }
+  *dst = s;
 }
 
 // ---- tiny-channel stem (cin < 8: conv0p1s1 has cin = 3): plain VALU, HBM-bound -----------------
@@ -431,7 +445,8 @@ static size_t partial_bytes(int64_t rows, int N, int K) {
 static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int cin, int cout,
                         bool w_transposed, int N, const pcmi_kmap_t* map, bool pair_mode,
                         bool swap_pairs, const int32_t* wsel, const float* bias, float* out,
-                        int64_t out_ld, int64_t n_rows, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int64_t out_ld, int64_t n_rows, int accumulate, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
   PCMI_REQUIRE(C % 32 == 0 && N % 32 == 0, PCMI_ERR_UNSUPPORTED,
                "spconv: channels (%d -> %d) must be multiples of 32 on the MFMA path", C, N);
   PCMI_REQUIRE(x_ld % 4 == 0 && out_ld >= N && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0),
@@ -460,6 +475,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   a.offs = nullptr;
   a.ksplit = 1;
   a.split_stride = 0;
+  a.accumulate = accumulate;
   a.out = out;
   a.out_ld = out_ld;
   if (pair_mode) {
@@ -485,6 +501,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
     a.out = (float*)ws;
     a.out_ld = N;
     a.bias = nullptr;
+    a.accumulate = 0;
   }
   dim3 grid((unsigned)ceil_div(n_rows, 32 * p.RW), (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
   int rc = w_transposed ? launch_rw<true, false>(p.RW, p.NT, a, grid, st)
@@ -493,7 +510,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   if (p.ksplit > 1) {
     const int64_t n4 = n_rows * (N / 4);
     split_reduce_kernel<<<dim3((unsigned)ceil_div(n4, 256)), 256, 0, st>>>((const float*)ws, a.split_stride, p.ksplit,
-                                                                         n_rows, N, bias, out, out_ld);
+                                                                         n_rows, N, bias, out, out_ld, accumulate);
     PCMI_LAUNCH_CHECK();
   }
   return PCMI_OK;
@@ -505,15 +522,12 @@ size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, 
 
 }  // namespace pcmi
 
-using namespace pcmi;
+namespace pcmi {
 
-extern "C" {
-
-int pcmi_spconv_fwd(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
-                    const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
-                    int64_t n_out, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+int spconv_forward(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
+                   const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
+                   int64_t n_out, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   PCMI_REQUIRE(in && weight && out && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_fwd: null/empty argument");
-  hipStream_t st = as_stream(stream);
   if (map) {
     const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
     PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_fwd: rows (%lld -> %lld) do not match the map (%lld -> %lld)",
@@ -522,7 +536,7 @@ int pcmi_spconv_fwd(const float* in, int64_t in_ld, int64_t n_in, int cin, const
     PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_fwd: dense path needs n_in == n_out");
   }
   if (cin < 8) {
-    PCMI_REQUIRE(cin == 3 && !transpose && (!map || map->stride == 1), PCMI_ERR_UNSUPPORTED,
+    PCMI_REQUIRE(cin == 3 && !transpose && !accumulate && (!map || map->stride == 1), PCMI_ERR_UNSUPPORTED,
                  "spconv_fwd: cin=%d only supported as the 3-channel stride-1 stem", cin);
     if (n_out == 0) return PCMI_OK;
     const int K = map ? map->K : 1;
@@ -536,18 +550,17 @@ int pcmi_spconv_fwd(const float* in, int64_t in_ld, int64_t n_in, int cin, const
   const bool pair_mode = map && transpose;
   PCMI_REQUIRE(!(map && transpose && map->stride != 2), PCMI_ERR_UNSUPPORTED, "spconv_fwd: transposed conv needs a stride-2 map");
   return run_gathered(in, in_ld, cin, weight, cin, cout, false, cout, map, pair_mode, false, nullptr, bias, out,
-                      out_ld, n_out, ws, ws_bytes, st);
+                      out_ld, n_out, accumulate, ws, ws_bytes, st);
 }
 
-int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
+int spconv_backward_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
                          const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
-                         void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+                         int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   PCMI_REQUIRE(gout && weight && gin && cin >= 8 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_data: bad argument (cin=%d)", cin);
-  hipStream_t st = as_stream(stream);
   if (!map) {
     PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_data: dense path needs n_in == n_out");
     return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, nullptr, false, false, nullptr, nullptr,
-                        gin, gin_ld, n_in, ws, ws_bytes, st);
+                        gin, gin_ld, n_in, accumulate, ws, ws_bytes, st);
   }
   const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
   PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_bwd_data: rows do not match the map");
@@ -555,16 +568,36 @@ int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int 
     // gin[i] = sum_k gout[nbr[k][i]] @ W[mirror(k)]^T  (in and out rows coincide)
     PCMI_REQUIRE(!transpose, PCMI_ERR_UNSUPPORTED, "spconv_bwd_data: transposed stride-1 conv is not on the hot path");
     return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, false, false, map->mirror, nullptr,
-                        gin, gin_ld, n_in, ws, ws_bytes, st);
+                        gin, gin_ld, n_in, accumulate, ws, ws_bytes, st);
   }
   if (!transpose) {
     // strided conv: every fine (input) row has exactly one (coarse row, k): pair mode, rows = fine
     return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, true, false, nullptr, nullptr, gin,
-                        gin_ld, n_in, ws, ws_bytes, st);
+                        gin_ld, n_in, accumulate, ws, ws_bytes, st);
   }
   // transposed conv: gin (coarse) gathers its children: nbr table, rows = coarse
   return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, false, false, nullptr, nullptr, gin,
-                      gin_ld, n_in, ws, ws_bytes, st);
+                      gin_ld, n_in, accumulate, ws, ws_bytes, st);
+}
+
+}  // namespace pcmi
+
+using namespace pcmi;
+
+extern "C" {
+
+int pcmi_spconv_fwd(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
+                    const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
+                    int64_t n_out, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  return spconv_forward(in, in_ld, n_in, cin, weight, cout, map, transpose, bias, out, out_ld, n_out, 0, ws, ws_bytes,
+                        as_stream(stream));
+}
+
+int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
+                         const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
+                         void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  return spconv_backward_data(gout, gout_ld, n_out, cout, weight, cin, map, transpose, gin, gin_ld, n_in, 0, ws,
+                              ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

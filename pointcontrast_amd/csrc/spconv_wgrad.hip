@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
 // gW[k][e] = sum over the chunks of offset k of slab[chunk][e]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, const int64_t* __restrict__ offs,
                                     int K, int64_t M, int chunk, int64_t per_k /* cin*cout */,
-                                    float* __restrict__ gw) {
+                                    float* __restrict__ gw, int accumulate) {
   const int k = blockIdx.y;
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= per_k) return;
@@ -211,7 +211,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, const int64
   }
   float s = 0.f;
   for (int64_t c = 0; c < count; ++c) s += slabs[(first + c) * per_k + e];
-  gw[(int64_t)k * per_k + e] = s;
+  float* dst = gw + (int64_t)k * per_k + e;
+  *dst = accumulate ? *dst + s : s;
 }
 
 // tiny-channel stem (cin = 3): slab[chunk][c][n] = sum_p x[i_p][c] * g[j_p][n]
@@ -274,12 +275,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nblocks, int c,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int accumulate) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= c) return;
   float s = 0.f;
   for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * c + col];
-  out[col] = s;
+  out[col] = accumulate ? out[col] + s : s;
 }
 
 template <int CT>
@@ -337,11 +338,13 @@ size_t pcmi_spconv_workspace_bytes(int64_t n_in, int64_t n_out, int cin, int cou
                   spconv_wgrad_workspace(n_in, n_out, cin, cout, K, M)) + 256;
 }
 
-int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+}  // extern "C"
+
+namespace pcmi {
+int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
                            int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
-                           float* gweight, float* gbias, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+                           float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   PCMI_REQUIRE(in && gout && gweight && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_weight: bad argument");
-  hipStream_t st = as_stream(stream);
   const int K = map ? map->K : 1;
   int64_t M;
   if (map) {
@@ -354,8 +357,10 @@ int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
   }
   const int64_t per_k = (int64_t)cin * cout;
   if (M == 0) {
-    PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
-    if (gbias) PCMI_HIP_CHECK(hipMemsetAsync(gbias, 0, sizeof(float) * cout, st));
+    if (!accumulate) {
+      PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
+      if (gbias) PCMI_HIP_CHECK(hipMemsetAsync(gbias, 0, sizeof(float) * cout, st));
+    }
     return PCMI_OK;
   }
   WgradArgs a;
@@ -397,7 +402,7 @@ int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
     if (rc) return rc;
   }
   wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per_k, 256), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
-                                                                                      per_k, gweight);
+                                                                                      per_k, gweight, accumulate);
   PCMI_LAUNCH_CHECK();
   if (gbias) {
     float* part = (float*)((char*)ws + align_up(slab_bytes, 256));
@@ -405,10 +410,21 @@ int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
     const int rows_per_block = (int)ceil_div(n_out, nblocks);
     colsum_partial_kernel<<<nblocks, 256, 0, st>>>(gout, gout_ld, n_out, cout, rows_per_block, part);
     PCMI_LAUNCH_CHECK();
-    colsum_final_kernel<<<dim3((unsigned)ceil_div(cout, 256)), 256, 0, st>>>(part, nblocks, cout, gbias);
+    colsum_final_kernel<<<dim3((unsigned)ceil_div(cout, 256)), 256, 0, st>>>(part, nblocks, cout, gbias, accumulate);
     PCMI_LAUNCH_CHECK();
   }
   return PCMI_OK;
+}
+
+}  // namespace pcmi
+
+extern "C" {
+
+int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                           int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
+                           float* gweight, float* gbias, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  return spconv_backward_weight(in, in_ld, n_in, cin, gout, gout_ld, n_out, cout, map, transpose, gweight, gbias, 0, ws,
+                                ws_bytes, as_stream(stream));
 }
 
 }  // extern "C"

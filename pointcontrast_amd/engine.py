@@ -1,0 +1,163 @@
+"""Native network executor: lowers a model built from the pointcontrast_amd.minkowski modules into
+a libpcmi network program (include/pcmi.h, "Network executor") and runs a whole forward or
+backward as ONE C call.
+
+The autograd path (functional.py) costs one Python autograd node + several ctypes calls per layer
+-- ~2000 launches and ~90 ms of host time per 4-pair iteration of Res16UNet34C, twice the GPU time.
+Here the module tree is traced once with symbolic tensors; per iteration the host does two
+pcmi_net_forward and two pcmi_net_backward calls plus the loss.  Same kernels, same arithmetic.
+"""
+import ctypes as C
+
+import torch
+
+from . import minkowski as ME
+from ._lib import lib, check, NetOp, NetTensor, READY_FN
+from .runtime import ptr, cur_stream, require_cuda
+
+OP_CONV, OP_BN, OP_L2NORM = 0, 1, 2
+
+
+class _Tracer:
+
+  def __init__(self, offset_of):
+    self.offset_of = offset_of  # id(parameter) -> offset in the flat buffer
+    self.tensors, self.ops, self.bn_modules = [], [], []
+
+  def new(self, channels, level):
+    self.tensors.append(dict(level=level, channels=channels, parent=-1, col_off=0))
+    return ME.SymTensor(self, len(self.tensors) - 1, channels, level)
+
+  def _off(self, p):
+    return self.offset_of[id(p)]
+
+  def conv(self, mod, x):
+    assert x.channels == mod.in_channels, "conv input width %d != %d" % (x.channels, mod.in_channels)
+    if mod.kernel_volume == 1:
+      level = x.level
+    elif mod.transpose:
+      level = x.level - 1
+    else:
+      level = x.level + (1 if mod.stride == 2 else 0)
+    out = self.new(mod.out_channels, level)
+    self.ops.append(dict(type=OP_CONV, in_=x.id, in2=-1, out=out.id, cin=mod.in_channels, cout=mod.out_channels,
+                         kernel_size=mod.kernel_size, stride=mod.stride, region=mod.kernel_generator.region_code,
+                         transpose=int(mod.transpose), relu=0, has_bias=int(mod.bias is not None),
+                         w_off=self._off(mod.kernel), b_off=self._off(mod.bias) if mod.bias is not None else 0))
+    return out
+
+  def bn(self, mod, x, residual, relu):
+    bn = mod.bn
+    out = self.new(x.channels, x.level)
+    self.ops.append(dict(type=OP_BN, in_=x.id, in2=residual.id if residual is not None else -1, out=out.id,
+                         cin=x.channels, cout=x.channels, relu=int(bool(relu)), w_off=self._off(bn.weight),
+                         b_off=self._off(bn.bias), running_mean=bn.running_mean.data_ptr(),
+                         running_var=bn.running_var.data_ptr(), momentum=float(bn.momentum), eps=float(bn.eps)))
+    self.bn_modules.append(mod)
+    return out
+
+  def cat(self, ts):
+    level = ts[0].level
+    parent = self.new(sum(t.channels for t in ts), level)
+    col = 0
+    for t in ts:
+      rec = self.tensors[t.id]
+      assert t.level == level and rec["parent"] == -1, "a tensor can be concatenated once, on its own level"
+      rec["parent"], rec["col_off"] = parent.id, col
+      col += t.channels
+    return parent
+
+  def l2norm(self, x):
+    out = self.new(x.channels, x.level)
+    self.ops.append(dict(type=OP_L2NORM, in_=x.id, in2=-1, out=out.id, cin=x.channels, cout=x.channels))
+    return out
+
+
+def lower_model(model, flat, in_channels=3):
+  """Traces `model` with a symbolic tensor; returns the program (ctypes arrays + metadata)."""
+  tr = _Tracer({id(p): off for p, off in zip(flat.params, flat.offsets)})
+  x = tr.new(in_channels, 0)
+  y = model(x)
+  assert isinstance(y, ME.SymTensor), "the model's forward did not stay symbolic"
+  T = (NetTensor * len(tr.tensors))()
+  for i, t in enumerate(tr.tensors):
+    T[i] = NetTensor(t["level"], t["channels"], t["parent"], t["col_off"])
+  O = (NetOp * len(tr.ops))()
+  for i, o in enumerate(tr.ops):
+    O[i] = NetOp(o["type"], o["in_"], o["in2"], o["out"], o.get("cin", 0), o.get("cout", 0), o.get("kernel_size", 0),
+                 o.get("stride", 1), o.get("region", 0), o.get("transpose", 0), o.get("relu", 0), o.get("has_bias", 0),
+                 o.get("w_off", 0), o.get("b_off", 0), o.get("running_mean", None), o.get("running_var", None),
+                 o.get("momentum", 0.0), o.get("eps", 0.0))
+  return dict(T=T, O=O, tensors=tr.tensors, ops=tr.ops, input=x.id, output=y.id, out_channels=y.channels,
+              n_down=max(t["level"] for t in tr.tensors), bn_modules=tr.bn_modules)
+
+
+def create_net(prog, n_passes=2):
+  h = C.c_void_p()
+  check(lib.pcmi_net_create(prog["T"], len(prog["tensors"]), prog["O"], len(prog["ops"]), prog["input"], prog["output"],
+                            n_passes, C.byref(h)))
+  return h
+
+
+class NativeEngine:
+  """model: a network of ME modules whose forward maps one SparseTensor to one SparseTensor
+  (Res16UNet family).  flat: lib.distributed.FlatParameters of the same model."""
+
+  def __init__(self, model, flat, in_channels=3, n_passes=2):
+    require_cuda(flat.w, "NativeEngine")
+    self.model, self.flat, self.n_passes = model, flat, n_passes
+    prog = lower_model(model, flat, in_channels)
+    self.in_channels, self.out_channels, self.n_down = in_channels, prog["out_channels"], prog["n_down"]
+    self._bn_modules = prog["bn_modules"]
+    self.n_ops, self.n_tensors = len(prog["ops"]), len(prog["tensors"])
+    self._h = create_net(prog, n_passes)
+    self._held = [None] * n_passes
+
+  def __del__(self):
+    try:
+      if getattr(self, "_h", None):
+        torch.cuda.synchronize()
+        lib.pcmi_net_destroy(self._h)
+        self._h = None
+    except Exception:
+      pass
+
+  def forward(self, pass_id, st, training=True):
+    """st: ME.SparseTensor on the device.  Returns the output features [N, out_channels]."""
+    x = st.F
+    require_cuda(x, "NativeEngine.forward")
+    x = x if (x.stride(1) == 1 and x.dtype == torch.float32) else x.float().contiguous()
+    cm = st.coords_man
+    cm.plan_unet(self.n_down)
+    n = x.shape[0]
+    out = torch.empty((n, self.out_channels), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+      check(lib.pcmi_net_forward(self._h, pass_id, cm._h, ptr(x), x.stride(0), n, ptr(self.flat.w), int(training), ptr(out),
+                                 self.out_channels, cur_stream(x.device)))
+    if training:
+      for m in self._bn_modules:
+        m._untracked += 1
+      self._held[pass_id] = (st, x, out)  # coordinates / input / output stay alive until backward
+    return out
+
+  def backward(self, pass_id, d_out, reducer=None):
+    """Accumulates parameter gradients of pass `pass_id` into flat.g.  With a GradReducer the
+    buckets are all-reduced (on its side stream) as soon as this pass completes them -- pass it
+    only on the LAST backward of the iteration."""
+    assert self._held[pass_id] is not None, "forward(training=True) first"
+    d = d_out if (d_out.stride(1) == 1 and d_out.stride(0) % 4 == 0) else d_out.contiguous()
+    cb, lo_arr, nb = READY_FN(), None, 0
+    if reducer is not None and reducer.world > 1:
+      order = sorted(range(len(reducer.buckets)), key=lambda b: reducer.buckets[b][0])
+      lo_arr = (C.c_int64 * len(order))(*[reducer.buckets[b][0] for b in order])
+      nb = len(order)
+      cb = READY_FN(lambda _ctx, q: reducer._launch(order[q]))
+    with torch.cuda.device(d.device):
+      check(lib.pcmi_net_backward(self._h, pass_id, ptr(d), d.stride(0), ptr(self.flat.w), ptr(self.flat.g), lo_arr, nb, cb,
+                                  None, cur_stream(d.device)))
+    self._held[pass_id] = None
+
+  def memory_bytes(self):
+    b = C.c_size_t()
+    check(lib.pcmi_net_memory_bytes(self._h, C.byref(b)))
+    return b.value

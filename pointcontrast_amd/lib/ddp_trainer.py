@@ -70,6 +70,12 @@ class ContrastiveLossTrainer:
     self.model = model
     self.flat = du.FlatParameters(model.parameters())
     self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", 32.0))
+    # misc.engine: "native" = whole forward / backward as one libpcmi call each (engine.py);
+    #              "autograd" = per-layer torch.autograd.Function path (same kernels)
+    self.engine = None
+    if config.misc.get("engine", "native") == "native":
+      from ..engine import NativeEngine
+      self.engine = NativeEngine(model, self.flat, in_channels=num_feats)
     self.optimizer = FlatSGD(self.flat, lr=config.opt.lr, momentum=config.opt.momentum,
                              weight_decay=config.opt.weight_decay, grad_scale=self.reducer.grad_scale)
     self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, config.opt.exp_gamma)
@@ -111,13 +117,23 @@ class ContrastiveLossTrainer:
   # -- shared pieces of one iteration ----------------------------------------------------------
   def _forward_pair(self, input_dict):
     s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device)
-    F0 = self.model(s0).F
+    if self.engine is None:
+      F0 = self.model(s0).F
+      s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
+      return F0, self.model(s1).F
     s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
-    F1 = self.model(s1).F
+    F0 = self.engine.forward(0, s0, self.model.training).requires_grad_(True)
+    F1 = self.engine.forward(1, s1, self.model.training).requires_grad_(True)
+    self._feats = (F0, F1)
     return F0, F1
 
   def _backward_and_step(self, loss, result):
-    loss.backward()
+    loss.backward()  # autograd path: through both networks; engine path: only down to F0 / F1
+    if self.engine is not None:
+      F0, F1 = self._feats
+      self.engine.backward(1, F1.grad)
+      self.engine.backward(0, F0.grad, reducer=self.reducer)  # last pass: buckets become final -> RCCL
+      self._feats = None
     self.reducer.finish()
     if self.world_size > 1:
       result = du.scaled_all_reduce_dict({k: v.detach().clone() for k, v in result.items()}, self.world_size)

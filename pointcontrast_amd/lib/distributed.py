@@ -111,6 +111,7 @@ class GradReducer:
           self.bucket_of[m] = b
         members, hi = [], lo
     self._pending = [0] * len(self.buckets)
+    self._launched = [False] * len(self.buckets)
     self._works = []
     self._hooks = []
     if self.world > 1:
@@ -126,6 +127,10 @@ class GradReducer:
     return hook
 
   def _launch(self, b):
+    """All-reduce bucket b now (autograd hook, or the native engine's ready callback)."""
+    if self.world == 1 or self._launched[b]:
+      return
+    self._launched[b] = True
     lo, hi, _ = self.buckets[b]
     chunk = self.flat.g[lo:hi]
     if self.cuda:
@@ -141,15 +146,15 @@ class GradReducer:
     """Call after backward: launches what is left and makes the compute stream wait for RCCL."""
     if self.world == 1:
       return
-    for b, cnt in enumerate(self._pending):
-      if cnt != self.buckets[b][2]:  # parameters that received no gradient this step
-        self._launch(b)
+    for b in range(len(self.buckets)):  # buckets whose parameters received no gradient this step
+      self._launch(b)
     for w in self._works:
       w.wait()
     if self.cuda:
       torch.cuda.current_stream(self.flat.g.device).wait_stream(self.comm_stream)
     self._works = []
     self._pending = [0] * len(self.buckets)
+    self._launched = [False] * len(self.buckets)
 
   @property
   def grad_scale(self):

@@ -200,6 +200,24 @@ class CoordsManager:
       check(lib.pcmi_coords_plan_unet(self._h, n_down, first_region, block_region, self._st()))
 
 
+class SymTensor:
+  """Stand-in for a SparseTensor while a model is being lowered to a libpcmi network program
+  (pointcontrast_amd/engine.py): the modules record ops on `tracer` instead of launching kernels."""
+
+  def __init__(self, tracer, tid, channels, level):
+    self.tracer, self.id, self.channels, self.level = tracer, tid, channels, level
+    self.coords_man = self.coords_key = None
+
+  @property
+  def F(self):
+    raise NotImplementedError("a model that touches .F directly cannot be lowered to the native engine")
+
+  def __add__(self, other):
+    raise NotImplementedError("use the fused MinkowskiBatchNorm(x, residual=...) form in models meant for the engine")
+
+  __iadd__ = __add__
+
+
 class SparseTensor:
   """ME.SparseTensor: a feature matrix plus (coords_key, coords_manager)
   (pc/lib/ddp_trainer.py:290-297,392-398; pc/model/res16unet.py:262-266).
@@ -318,6 +336,8 @@ class _ConvBase(nn.Module):
         self.bias.uniform_(-stdv, stdv)
 
   def forward(self, x):
+    if isinstance(x, SymTensor):
+      return x.tracer.conv(self, x)
     assert isinstance(x, SparseTensor)
     cm, in_key = x.coords_man, x.coords_key
     assert cm is not None, "move the SparseTensor to the GPU first (.to(device))"
@@ -379,6 +399,8 @@ class MinkowskiBatchNorm(nn.Module):
 
   def forward(self, x, residual=None, relu=False):
     """``residual`` / ``relu`` select the fused epilogue (the unfused call is forward(x))."""
+    if isinstance(x, SymTensor):
+      return x.tracer.bn(self, x, residual, relu)
     bn = self.bn
     res = residual.F if residual is not None else None
     if self.training:
@@ -396,16 +418,27 @@ class MinkowskiReLU(nn.Module):
     super().__init__()
 
   def forward(self, x):
+    if isinstance(x, SymTensor):
+      raise NotImplementedError("standalone ReLU is not lowered; use MinkowskiBatchNorm(x, relu=True)")
     return SparseTensor(PF.ReLUFunction.apply(x.F), coords_key=x.coords_key, coords_manager=x.coords_man)
 
 
 def cat(*tensors):
   """MinkowskiOps.cat: channel concat of tensors on one coordinate set
   (pc/model/res16unet.py:235,242,249,256).  The copy is a torch.cat (memory plumbing)."""
+  if isinstance(tensors[0], SymTensor):
+    return tensors[0].tracer.cat(tensors)
   key = tensors[0].coords_key
   for t in tensors:
     assert t.coords_key == key, "cat: tensors must share coords_key"
   return SparseTensor(torch.cat([t.F for t in tensors], dim=1), coords_key=key, coords_manager=tensors[0].coords_man)
+
+
+def l2_normalize(x):
+  """F / ||F||_2 per row on the same coordinates (pc/model/res16unet.py:262-266)."""
+  if isinstance(x, SymTensor):
+    return x.tracer.l2norm(x)
+  return SparseTensor(PF.L2NormalizeFunction.apply(x.F), coords_key=x.coords_key, coords_manager=x.coords_man)
 
 
 def _sparse_quantize(coords, feats=None, labels=None, return_index=False, quantization_size=None):

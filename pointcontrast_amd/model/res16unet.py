@@ -6,7 +6,6 @@ Module and parameter names match the reference so checkpoints interchange
 BatchNorm+ReLU pairs run as one fused libpcmi kernel.
 """
 from .. import minkowski as ME
-from ..functional import L2NormalizeFunction
 from .modules.common import ConvType, NormType, conv, conv_tr, get_norm
 from .modules.resnet_block import BasicBlock
 from .resnet import ResNetBase
@@ -72,10 +71,7 @@ class Res16UNetBase(ResNetBase):
       out = ME.MinkowskiOps.cat(out, skips.pop())
       out = getattr(self, blk)(out)
     out = self.final(out)
-    if self.normalize_feature:
-      return ME.SparseTensor(L2NormalizeFunction.apply(out.F), coords_key=out.coords_key,
-                             coords_manager=out.coords_man)
-    return out
+    return ME.l2_normalize(out) if self.normalize_feature else out
 
 
 class Res16UNet14(Res16UNetBase):

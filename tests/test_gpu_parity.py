@@ -474,6 +474,52 @@ def test_network_features_loss_and_grads(ME, name, crop, batch):
   assert_close(dev.block8[-1].norm2.bn.running_var, ref.block8[-1].norm2.bn.running_var, 1e-4, "block8 running var")
 
 
+@pytest.mark.parametrize("name,crop,batch", [("Res16UNet14", 0.6, 1), ("Res16UNet34C", 0.9, 2)])
+def test_engine_matches_autograd_path(ME, name, crop, batch):
+  """The native executor (one C call per forward / backward) against the per-layer autograd path:
+  same kernels, so features agree to fp32 round-off and parameter gradients to accumulation order."""
+  from pointcontrast_amd.engine import NativeEngine
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.distributed import FlatParameters
+  cfg = get_config([])
+  _, dev = _make_models(name, cfg, seed=3)
+  dev.train()
+  flat = FlatParameters(dev.parameters())
+  eng = NativeEngine(dev, flat)
+  b = synthetic.make_batch(seed=6, batch_size=batch, crop=crop)
+  sts = [ME.SparseTensor(torch.from_numpy(b["sinput%s_F" % s]), coords=torch.from_numpy(b["sinput%s_C" % s])).to(DEV) for s in "01"]
+  rs = {k: v.clone() for k, v in dev.state_dict().items() if "running" in k}
+  fa = [dev(st).F for st in sts]
+  g = [torch.randn_like(f) for f in fa]
+  flat.zero_grad()
+  (fa[0] * g[0]).sum().backward()
+  (fa[1] * g[1]).sum().backward()
+  ga = flat.g.clone()
+  rs_after = {k: v.clone() for k, v in dev.state_dict().items() if "running" in k}
+  dev.load_state_dict({**dev.state_dict(), **rs})  # rewind the BN running statistics
+  fe = [eng.forward(i, sts[i]) for i in range(2)]
+  for i in range(2):
+    assert_close(fe[i], fa[i], 1e-5, "%s engine features pass %d" % (name, i))
+  flat.zero_grad()
+  eng.backward(1, g[1])
+  eng.backward(0, g[0])
+  scale = float(ga.abs().max())
+  per = []
+  for i, p in enumerate(flat.params):
+    a, e = flat.view(ga, i), flat.view(flat.g, i)
+    per.append((float((a - e).abs().max()) / max(float(a.abs().max()), 1e-4 * scale), i))
+  per.sort(reverse=True)
+  names = {id(p): n for n, p in dev.named_parameters()}
+  msg = "; ".join("%s %.2e" % (names[id(flat.params[i])], e) for e, i in per[:5])
+  print("engine vs autograd worst gradient tensors:", msg)
+  assert per[0][0] <= 2e-3, msg
+  for k, v in dev.state_dict().items():
+    if "running" in k:
+      assert_close(v, rs_after[k], 1e-5, "engine " + k)
+  assert eng.memory_bytes() > 0
+
+
 @pytest.mark.parametrize("which", ["nce", "hardest"])
 def test_trainer_iteration_matches_oracle(which):
   """Two full iterations (2 forwards, loss, backward, SGD) of the device trainer against the
@@ -484,7 +530,8 @@ def test_trainer_iteration_matches_oracle(which):
   from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader, default_collate_pair_fn
   from pointcontrast_amd.lib import ddp_trainer
   cfg = get_config(["net.model=Res16UNet14", "misc.nceT=0.4", "misc.npos=256", "opt.lr=0.1",
-                    "trainer.num_pos_per_batch=256", "trainer.num_hn_samples_per_batch=128"])
+                    "trainer.num_pos_per_batch=256", "trainer.num_hn_samples_per_batch=128",
+                    "misc.engine=%s" % ("native" if which == "nce" else "autograd")])
   rng = np.random.RandomState(9)
   batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.7) for _ in range(2)])
   loader = FixedBatchLoader([batch], batch_size=2)

@@ -105,3 +105,27 @@ def test_pair_selection_matches_oracle():
   b = lr.nce_select_pairs(pp, u, si)
   assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
   assert (_hash(pp.astype(np.int64), 1000) == lr.hash_pairs(pp[:, 0], pp[:, 1], 1000)).all()
+
+
+def test_model_lowers_to_a_valid_network_program(built_lib):
+  """Tracing + pcmi_net_create need no GPU: the static program of Res16UNet34C is well formed
+  (every gradient contribution is either a first write or a full accumulate, slices fit)."""
+  from pointcontrast_amd._lib import lib, check
+  from pointcontrast_amd.engine import create_net, lower_model
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.distributed import FlatParameters
+  from pointcontrast_amd.model import load_model
+  cfg = get_config([])
+  for name, n_conv in (("Res16UNet14", 33), ("Res16UNet34C", 63)):
+    model = load_model(name)(3, 32, cfg, D=3)
+    flat = FlatParameters(model.parameters())
+    prog = lower_model(model, flat)
+    kinds = [o["type"] for o in prog["ops"]]
+    assert kinds.count(0) == n_conv and kinds.count(2) == 1 and prog["out_channels"] == 32 and prog["n_down"] == 4
+    assert kinds.count(1) == n_conv - 1  # every conv but the head is followed by a BatchNorm
+    cats = [t for t in prog["tensors"] if t["parent"] >= 0]
+    assert len(cats) == 8  # 4 concatenations, 2 slices each, zero copy
+    h = create_net(prog)
+    check(lib.pcmi_net_destroy(h))
+    offs = sorted(o["w_off"] for o in prog["ops"] if o["type"] == 0)
+    assert len(set(offs)) == n_conv and offs[0] == 0
