@@ -30,6 +30,10 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
   timeout 900 python bench.py --steps $STEPS --warmup $WARM --layer-table gpurun_out/layer_table.tsv ${BENCH_ARGS:-} > gpurun_out/bench.log 2>&1
   echo "bench exit: $?" >> gpurun_out/bench.log
   tail -3 gpurun_out/bench.log
+  if [ "${BENCH_AUTOGRAD:-1}" = "1" ]; then
+    timeout 600 python bench.py --steps $STEPS --warmup $WARM --engine autograd --no-roofline --no-cpu-baseline > gpurun_out/bench_autograd.log 2>&1
+    tail -1 gpurun_out/bench_autograd.log
+  fi
 fi
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   cd /tmp
