@@ -29,6 +29,7 @@
 //   tiles (+ optional split of the offset range over blockIdx.z into a partial buffer) so
 //   that the small, wide levels still fill 256 CUs.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -61,7 +62,7 @@ struct ConvArgs {
   int accumulate;        // out += result instead of out = result (only when ksplit == 1)
 };
 
-template <int NT, int RW, bool WT, bool PAIR>
+template <int NT, int RW, bool WT, bool PAIR, int DEPTH>
 __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
   constexpr int TM = 32 * RW;        // rows per workgroup tile
   constexpr int KG = 4 / RW;         // wave groups splitting the contraction blocks
@@ -197,8 +198,10 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
       }
     }
   };
-  float4 acur[BPG], anext[BPG];
-  bool vcur = false, vnext = false;
+  // A operands live in a three-deep register ring (gathers are the long-latency loads: HBM / far-L2
+  // misses), B chunks are one step ahead through LDS (weights are L2 hits shared by every workgroup).
+  float4 a0[BPG], a1[BPG], a2[BPG];
+  bool v0 = false, v1 = false, v2 = false;
   auto load_a = [&](int step, float4* dst) -> bool {
     const int kslot = s_klist[step / nch];
     const int c0 = (step % nch) * kKC;
@@ -218,20 +221,23 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
   // ---- main loop --------------------------------------------------------------------------
   if (nsteps > 0) {
     load_b(0);
-    vcur = load_a(0, acur);
+    v0 = load_a(0, a0);
+    if (DEPTH == 3 && nsteps > 1) v1 = load_a(1, a1);
     store_b(0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
       const bool more = step + 1 < nsteps;
-      if (more) {
-        load_b(step + 1);
-        vnext = load_a(step + 1, anext);
+      if (more) load_b(step + 1);
+      if (DEPTH == 3) {
+        if (step + 2 < nsteps) v2 = load_a(step + 2, a2);
+      } else {
+        if (more) v1 = load_a(step + 1, a1);
       }
-      if (vcur) {
+      if (v0) {
         const float* sb = s_f + (step & 1) * (kKC * LDB) + r;
 #pragma unroll
         for (int b = 0; b < BPG; ++b) {
-          const float av[4] = {acur[b].x, acur[b].y, acur[b].z, acur[b].w};
+          const float av[4] = {a0[b].x, a0[b].y, a0[b].z, a0[b].w};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const float* brow = sb + (8 * (kg * BPG + b) + 4 * h + s) * LDB;
@@ -243,11 +249,13 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
       }
       if (more) store_b((step + 1) & 1);
       __syncthreads();
-      if (more) {
 #pragma unroll
-        for (int b = 0; b < BPG; ++b) acur[b] = anext[b];
-        vcur = vnext;
+      for (int b = 0; b < BPG; ++b) {
+        a0[b] = a1[b];
+        if (DEPTH == 3) a1[b] = a2[b];
       }
+      v0 = v1;
+      if (DEPTH == 3) v1 = v2;
     }
   }
 
@@ -365,9 +373,24 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 
+// A-operand prefetch depth: 3 = gathers two steps ahead (more registers, 2 waves/SIMD),
+// 2 = one step ahead (3 waves/SIMD).  PCMI_SPCONV_DEPTH overrides the per-regime default.
+static int g_depth_override = -1;
+static int prefetch_depth(int RW) {
+  if (g_depth_override < 0) {
+    const char* e = getenv("PCMI_SPCONV_DEPTH");
+    g_depth_override = e ? atoi(e) : 0;
+  }
+  if (g_depth_override == 2 || g_depth_override == 3) return g_depth_override;
+  return RW == 4 ? 3 : 2;
+}
+
 template <int NT, int RW, bool WT, bool PAIR>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  spconv_mfma_kernel<NT, RW, WT, PAIR><<<grid, 256, 0, st>>>(a);
+  if (prefetch_depth(RW) == 3)
+    spconv_mfma_kernel<NT, RW, WT, PAIR, 3><<<grid, 256, 0, st>>>(a);
+  else
+    spconv_mfma_kernel<NT, RW, WT, PAIR, 2><<<grid, 256, 0, st>>>(a);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -398,7 +421,7 @@ static int launch_rw(int RW, int NT, const ConvArgs& a, dim3 grid, hipStream_t s
 struct Plan {
   int RW, NT, ksplit;
 };
-constexpr int kMaxKSplit = 9;
+constexpr int kMaxKSplit = 27;
 
 static int g_num_cu = 0;
 static int num_cu() {
@@ -428,7 +451,7 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair) {
     // small levels: narrower slices and a split of the offset range until the chip is full
     if (p.NT > 2) p.NT = (nt_all % 2 == 0) ? 2 : 1;
     const int64_t wgs = ceil_div(rows, 32) * (nt_all / p.NT);
-    const int64_t target = 2 * num_cu();
+    const int64_t target = 6 * num_cu();  // latency-bound steps: several resident workgroups per CU
     if (!pair && K > 1 && wgs < target)
       p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
   }

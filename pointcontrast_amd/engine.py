@@ -147,7 +147,7 @@ class NativeEngine:
     assert self._held[pass_id] is not None, "forward(training=True) first"
     d = d_out if (d_out.stride(1) == 1 and d_out.stride(0) % 4 == 0) else d_out.contiguous()
     cb, lo_arr, nb = READY_FN(), None, 0
-    if reducer is not None and reducer.world > 1:
+    if reducer is not None and reducer.active:
       order = sorted(range(len(reducer.buckets)), key=lambda b: reducer.buckets[b][0])
       lo_arr = (C.c_int64 * len(order))(*[reducer.buckets[b][0] for b in order])
       nb = len(order)

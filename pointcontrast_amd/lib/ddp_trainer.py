@@ -58,6 +58,11 @@ class ContrastiveLossTrainer:
     assert config.misc.use_gpu and torch.cuda.is_available(), "the pre-training path runs on a gfx950 GPU"
     num_feats = 3  # ones (+ jitter), pc/lib/ddp_data_loaders.py:248-252
     self.config = config
+    # The host side of an iteration is a few small torch-CPU / numpy ops (pair selection, index staging).
+    # On a many-core host torch's default intra-op pool (one thread per core) makes each of them cost tens of
+    # milliseconds of thread wake-ups; a handful of threads is faster and leaves the cores to the loader workers.
+    if torch.get_num_threads() > config.misc.get("host_threads", 8):
+      torch.set_num_threads(config.misc.get("host_threads", 8))
     self.world_size = du.get_world_size()
     self.is_master = du.is_master_proc()
     self.cur_device = torch.device("cuda", torch.cuda.current_device())
@@ -69,7 +74,8 @@ class ContrastiveLossTrainer:
         torch.distributed.broadcast(p.data, src=0)
     self.model = model
     self.flat = du.FlatParameters(model.parameters())
-    self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", 32.0))
+    self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", 32.0),
+                                   force=config.misc.get("force_reducer", False))
     # misc.engine: "native" = whole forward / backward as one libpcmi call each (engine.py);
     #              "autograd" = per-layer torch.autograd.Function path (same kernels)
     self.engine = None
@@ -114,6 +120,26 @@ class ContrastiveLossTrainer:
       os.remove(link)
     os.symlink(filename + ".pth", link)
 
+  def _upload(self, idx_cpu, slot):
+    """Index vector -> device through a persistent pinned staging buffer: the copy is truly
+    asynchronous (a pageable H2D copy would block the host until the stream has drained)."""
+    n = idx_cpu.numel()
+    st = getattr(self, "_staging", None)
+    if st is None:
+      st = self._staging = {}
+    buf, ev = st.get(slot, (None, None))
+    if buf is None or buf.numel() < n:
+      buf = torch.empty(max(n, 8192), dtype=torch.int64).pin_memory()
+      ev = None
+    if ev is not None:
+      ev.synchronize()  # the previous iteration's copy out of this buffer (long finished)
+    buf[:n].copy_(idx_cpu.reshape(-1))
+    out = buf[:n].to(self.cur_device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st[slot] = (buf, ev)
+    return out.view(idx_cpu.shape)
+
   # -- shared pieces of one iteration ----------------------------------------------------------
   def _forward_pair(self, input_dict):
     s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device)
@@ -135,7 +161,7 @@ class ContrastiveLossTrainer:
       self.engine.backward(0, F0.grad, reducer=self.reducer)  # last pass: buckets become final -> RCCL
       self._feats = None
     self.reducer.finish()
-    if self.world_size > 1:
+    if self.world_size > 1 or self.reducer.active:
       result = du.scaled_all_reduce_dict({k: v.detach().clone() for k, v in result.items()}, self.world_size)
     self.optimizer.step()
     return result
@@ -238,14 +264,21 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     RNG on the host; the correspondences arrive on the host anyway, so the whole selection
     is host-side here (identical arithmetic: fp32 floor(u * count)) and only the two index
     vectors are uploaded."""
-    pp = pos_pairs if torch.is_tensor(pos_pairs) else torch.as_tensor(np.asarray(pos_pairs))
-    pp = pp.long().cpu()
-    q_unique, count = pp[:, 0].unique(return_counts=True)
+    pp = pos_pairs.numpy() if torch.is_tensor(pos_pairs) else np.asarray(pos_pairs)
+    col0 = pp[:, 0].astype(np.int64, copy=False)
+    col1 = pp[:, 1].astype(np.int64, copy=False)
+    if len(col0) > 1 and (np.diff(col0) < 0).any():  # the loader's contract is "sorted by query row"
+      order = np.argsort(col0, kind="stable")
+      col0, col1 = col0[order], col1[order]
+    # unique(return_counts=True) of a sorted column = its run starts / run lengths (single pass, no sort)
+    starts = np.flatnonzero(np.concatenate([[True], col0[1:] != col0[:-1]])) if len(col0) else np.zeros(0, np.int64)
+    count = torch.from_numpy(np.diff(np.concatenate([starts, [len(col0)]])).astype(np.int64))
+    q_unique = torch.from_numpy(col0[starts])
     draws = draws or {}
     uniform = draws["uniform"] if "uniform" in draws else torch.distributions.Uniform(0, 1).sample([len(count)])
     off = torch.floor(torch.as_tensor(uniform, dtype=torch.float32) * count).long()
-    cums = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(count, dim=0)[:-1]])
-    k_sel = pp[:, 1][off + cums]
+    cums = torch.from_numpy(starts.astype(np.int64))  # exclusive cumsum of the counts
+    k_sel = torch.from_numpy(col1)[off + cums]
     if npos < q_unique.shape[0]:
       si = draws["sampled_inds"] if "sampled_inds" in draws else np.random.choice(q_unique.shape[0], npos, replace=False)
       si = torch.as_tensor(np.asarray(si)).long()
@@ -262,8 +295,8 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     data_time = data_timer.toc(average=False)
     F0, F1 = self._forward_pair(input_dict)
     q_idx, k_idx = self.select_pairs(input_dict["correspondences"], self.npos, draws)
-    q = PF.GatherRowsFunction.apply(F0, q_idx.to(self.cur_device, non_blocking=True))
-    k = PF.GatherRowsFunction.apply(F1, k_idx.to(self.cur_device, non_blocking=True))
+    q = PF.GatherRowsFunction.apply(F0, self._upload(q_idx, 0))
+    k = PF.GatherRowsFunction.apply(F1, self._upload(k_idx, 1))
     loss = PF.NCELossFunction.apply(q, k, self.T)
     result = self._backward_and_step(loss, {"loss": loss.detach()})
     total_timer.toc()

@@ -91,9 +91,12 @@ class FlatParameters:
 class GradReducer:
   """Bucketed all-reduce(SUM) of FlatParameters.g overlapped with backward."""
 
-  def __init__(self, flat, bucket_mb=32.0, process_group=None):
+  def __init__(self, flat, bucket_mb=32.0, process_group=None, force=False):
     self.flat, self.pg = flat, process_group
     self.world = get_world_size()
+    # force: run the bucketed all-reduce even in a 1-rank group (exercises the RCCL / side-stream path)
+    self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+    self.n_launched_total = 0
     self.cuda = flat.g.is_cuda
     self.comm_stream = torch.cuda.Stream(device=flat.g.device) if self.cuda else None
     cap = int(bucket_mb * (1 << 20) / 4)
@@ -114,7 +117,7 @@ class GradReducer:
     self._launched = [False] * len(self.buckets)
     self._works = []
     self._hooks = []
-    if self.world > 1:
+    if self.active:
       for i, p in enumerate(flat.params):
         self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
 
@@ -128,9 +131,10 @@ class GradReducer:
 
   def _launch(self, b):
     """All-reduce bucket b now (autograd hook, or the native engine's ready callback)."""
-    if self.world == 1 or self._launched[b]:
+    if not self.active or self._launched[b]:
       return
     self._launched[b] = True
+    self.n_launched_total += 1
     lo, hi, _ = self.buckets[b]
     chunk = self.flat.g[lo:hi]
     if self.cuda:
@@ -144,7 +148,7 @@ class GradReducer:
 
   def finish(self):
     """Call after backward: launches what is left and makes the compute stream wait for RCCL."""
-    if self.world == 1:
+    if not self.active:
       return
     for b in range(len(self.buckets)):  # buckets whose parameters received no gradient this step
       self._launch(b)

@@ -13,7 +13,7 @@ WARM=${WARM:-3}
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { echo "build failed"; tail -5 gpurun_out/build.log; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
   : > gpurun_out/pytest_gpu.log
-  GROUPS_DEFAULT="maps_ single_voxel spconv_parity stem_conv spconv_golden batchnorm bn_eval nce_parity gather_scatter pdist hardest_loss sgd_step network_features engine_matches trainer_iteration full_size"
+  GROUPS_DEFAULT="maps_ single_voxel spconv_parity stem_conv spconv_golden batchnorm bn_eval nce_parity gather_scatter pdist hardest_loss sgd_step network_features engine_matches trainer_iteration rccl_reducer full_size"
   for grp in ${TEST_GROUPS:-$GROUPS_DEFAULT}; do
     echo "=== group $grp" >> gpurun_out/pytest_gpu.log
     timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "$grp" >> gpurun_out/pytest_gpu.log 2>&1

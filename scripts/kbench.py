@@ -1,0 +1,57 @@
+"""Kernel micro-benchmark on the real maps of the bench batch: conv fwd / bwd-data / bwd-weight for the
+layer shapes of Res16UNet34C at every level (HIP events on the launch stream).  Usage on the GPU box:
+  PCMI_SPCONV_DEPTH=2 python scripts/kbench.py ; PCMI_SPCONV_DEPTH=3 python scripts/kbench.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import pointcontrast_amd.minkowski as ME
+from pointcontrast_amd._lib import lib, check
+from pointcontrast_amd.runtime import ptr, cur_stream, ws_args
+
+dev = torch.device("cuda:0")
+batch = bench.get_batch(0, 4, 0.025)
+st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(dev)
+cm = st.coords_man
+cm.plan_unet(4)
+keys = [st.coords_key]
+for _ in range(4):
+  keys.append(cm.stride(keys[-1], 2))
+print("depth env", os.environ.get("PCMI_SPCONV_DEPTH"), "rows", [cm.size(k) for k in keys], flush=True)
+tot = {}
+
+
+def run(label, kmap, K, cin, cout, n_in, n_out, transpose=0):
+  W = torch.randn((K, cin, cout) if K > 1 else (cin, cout), device=dev) * 0.05
+  x, g = torch.randn(n_in, cin, device=dev), torch.randn(n_out, cout, device=dev)
+  y, gin, gw = torch.empty(n_out, cout, device=dev), torch.empty(n_in, cin, device=dev), torch.empty_like(W)
+  M = kmap.M if kmap is not None else n_in
+  ws, wsb = ws_args(lib.pcmi_spconv_workspace_bytes(n_in, n_out, cin, cout, K, M), dev)
+  kr = C.byref(kmap) if kmap is not None else None
+  s = cur_stream(dev)
+  f = lambda: check(lib.pcmi_spconv_fwd(ptr(x), cin, n_in, cin, ptr(W), cout, kr, transpose, None, ptr(y), cout, n_out, ws, wsb, s))
+  b = lambda: check(lib.pcmi_spconv_bwd_data(ptr(g), cout, n_out, cout, ptr(W), cin, kr, transpose, ptr(gin), cin, n_in, ws, wsb, s))
+  w = lambda: check(lib.pcmi_spconv_bwd_weight(ptr(x), cin, n_in, cin, ptr(g), cout, n_out, cout, kr, transpose, ptr(gw), None, ws, wsb, s))
+  tf, tb, tw = (bench.time_kernel(k, iters=10, warm=2) * 1e3 for k in (f, b, w))
+  gf = 2 * M * cin * cout * 1e-9
+  print("%-34s M=%8d  fwd %7.3f ms %6.1f TF | bwd %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF" %
+        (label, M, tf, gf / tf, tb, gf / tb, tw, gf / tw), flush=True)
+  for k, v in (("fwd", tf), ("bwd", tb), ("wgrad", tw)):
+    tot[k] = tot.get(k, 0) + v
+
+
+shapes = {0: [(128, 96), (96, 96), (32, 32)], 1: [(32, 32), (128, 96), (96, 96)], 2: [(32, 64), (64, 64), (192, 128), (128, 128)],
+          3: [(64, 128), (128, 128), (384, 256), (256, 256)], 4: [(128, 256), (256, 256)]}
+for lvl, lst in shapes.items():
+  m = cm.kernel_map(keys[lvl], keys[lvl], 3, 1, 3)
+  n = cm.size(keys[lvl])
+  for cin, cout in lst:
+    run("L%d 3^3 %d->%d" % (lvl, cin, cout), m, 27, cin, cout, n, n)
+for lvl, (c, cu_in, cu_out) in enumerate([(32, 96, 96), (32, 128, 96), (64, 256, 128), (128, 256, 256)]):
+  m2 = cm.kernel_map(keys[lvl], keys[lvl + 1], 2, 2, 0)
+  run("L%d->%d 2^3/s2 %d->%d" % (lvl, lvl + 1, c, c), m2, 8, c, c, m2.n_in, m2.n_out)
+  run("L%d->%d 2^3/s2^T %d->%d" % (lvl + 1, lvl, cu_in, cu_out), m2, 8, cu_in, cu_out, m2.n_out, m2.n_in, 1)
+n0 = cm.size(keys[0])
+run("L0 1x1 128->96", None, 1, 128, 96, n0, n0)
+run("L0 1x1 96->32", None, 1, 96, 32, n0, n0)
+print("sum of the listed shapes: fwd %.2f ms, bwd %.2f ms, wgrad %.2f ms" % (tot["fwd"], tot["bwd"], tot["wgrad"]))

@@ -580,6 +580,48 @@ def test_trainer_iteration_matches_oracle(which):
   assert report[0][0] <= 5e-2, "state after 2 steps: " + msg
 
 
+def test_rccl_reducer_path_single_rank():
+  """The N>1 code path (bucket-ready callbacks from the native engine -> RCCL all-reduce on the side
+  stream -> compute stream waits -> scaled loss all-reduce) exercised in a 1-rank nccl group: it must
+  reproduce the plain single-process iteration exactly (sum over one rank, scale 1/1)."""
+  import os
+  import socket
+  import torch.distributed as dist
+  from pointcontrast_amd.lib import synthetic, ddp_trainer, distributed as du
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader, default_collate_pair_fn
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+  du.init_process_group(0, 1)
+  try:
+    rng = np.random.RandomState(2)
+    batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.7) for _ in range(2)])
+    losses = {}
+    for force in (False, True):
+      cfg = get_config(["net.model=Res16UNet14", "misc.nceT=0.4", "misc.npos=256", "misc.bucket_mb=4",
+                        "misc.force_reducer=%s" % force])
+      torch.manual_seed(7)
+      tr = ddp_trainer.PointNCELossTrainer(cfg, FixedBatchLoader([batch], 2))
+      pp = batch["correspondences"].numpy()
+      nq = len(np.unique(pp[:, 0]))
+      out = []
+      for step in range(2):
+        draws = dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(step)),
+                     sampled_inds=np.random.RandomState(step).choice(nq, 256, replace=False))
+        out.append(float(tr._train_iter(iter(FixedBatchLoader([batch], 2)), [AverageMeter(), Timer(), Timer()], draws=draws)["loss"]))
+      losses[force] = out
+      if force:
+        assert tr.reducer.active and len(tr.reducer.buckets) >= 3
+        assert tr.reducer.n_launched_total == 2 * len(tr.reducer.buckets)
+    assert losses[True] == losses[False], losses
+  finally:
+    du.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------------
 # full-size properties (no oracle needed): BASELINE config #2 shape, ~85k voxels per cloud
 # ------------------------------------------------------------------------------------------------
