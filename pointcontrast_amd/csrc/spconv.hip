@@ -382,12 +382,16 @@ static int prefetch_depth(int RW) {
     g_depth_override = e ? atoi(e) : 0;
   }
   if (g_depth_override == 2 || g_depth_override == 3) return g_depth_override;
-  return RW == 4 ? 3 : 2;
+  (void)RW;
+  return 0;  // per-variant default, see launch_one
 }
 
 template <int NT, int RW, bool WT, bool PAIR>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  if (prefetch_depth(RW) == 3)
+  // measured on the 96->96 level-1 conv: depth 3 wins with transposed weights (0.49 vs 0.61 ms), depth 2
+  // (one more resident wave per SIMD) without (0.48 vs 0.64 ms)
+  const int d = prefetch_depth(RW);
+  if (d == 3 || (d == 0 && WT))
     spconv_mfma_kernel<NT, RW, WT, PAIR, 3><<<grid, 256, 0, st>>>(a);
   else
     spconv_mfma_kernel<NT, RW, WT, PAIR, 2><<<grid, 256, 0, st>>>(a);
@@ -435,33 +439,30 @@ static int num_cu() {
   return g_num_cu;
 }
 
-// rows: output rows (or pairs in pair mode); N: output channels; K: offsets
+// rows: output rows (or pairs in pair mode); N: output channels; K: offsets.
+// Row tiles stay as large as the row count allows (a tile streams its weight slice once, so small
+// tiles multiply the weight traffic: measured 10-20 TFLOP/s with 32-row tiles on the 256-channel
+// levels); the parallelism the small levels lack comes from splitting the offset range over
+// blockIdx.z into partial sums instead.
 static Plan make_plan(int64_t rows, int N, int K, bool pair) {
   Plan p;
   const int nt_all = N / 32;
   p.NT = nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
   p.ksplit = 1;
-  if (rows >= 32768)
-    p.RW = 4;
-  else if (rows >= 8192)
-    p.RW = 2;
-  else
-    p.RW = 1;
-  if (p.RW == 1) {
-    // small levels: narrower slices and a split of the offset range until the chip is full
-    if (p.NT > 2) p.NT = (nt_all % 2 == 0) ? 2 : 1;
-    const int64_t wgs = ceil_div(rows, 32) * (nt_all / p.NT);
-    const int64_t target = 6 * num_cu();  // latency-bound steps: several resident workgroups per CU
-    if (!pair && K > 1 && wgs < target)
-      p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
+  p.RW = rows >= 96 ? 4 : (rows >= 48 ? 2 : 1);
+  if (p.RW == 1 && p.NT > 2) p.NT = (nt_all % 2 == 0) ? 2 : 1;  // the cross-wave reduction lives in LDS
+  if (!pair && K > 1) {
+    const int64_t wgs = ceil_div(rows, 32 * p.RW) * (nt_all / p.NT);
+    const int64_t target = (5 * (int64_t)num_cu()) / 2;
+    if (wgs < target) p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
   }
   return p;
 }
 
 static size_t partial_bytes(int64_t rows, int N, int K) {
-  // upper bound of make_plan's ksplit partial buffers, only for the RW == 1 regime
-  if (rows >= 8192 || K <= 1) return 0;
-  return (size_t)std::min(K, kMaxKSplit) * rows * N * sizeof(float);
+  if (K <= 1 || rows <= 0 || N % 32 != 0) return 0;
+  const Plan p = make_plan(rows, N, K, false);
+  return p.ksplit > 1 ? (size_t)p.ksplit * rows * N * sizeof(float) : 0;
 }
 
 // One gathered GEMM:  out[rows, N] = sum_k x[idx_k(rows)] @ B_k

@@ -195,13 +195,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
   }
 }
 
-// gW[k][e] = sum over the chunks of offset k of slab[chunk][e]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, const int64_t* __restrict__ offs,
-                                    int K, int64_t M, int chunk, int64_t per_k /* cin*cout */,
-                                    float* __restrict__ gw, int accumulate) {
+// gW[k][e] = sum over the chunks of offset k of slab[chunk][e].  32 elements x 8 chunk lanes per
+// workgroup: the chunk loop of one output is split 8 ways and folded through LDS in fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
+                                                           const int64_t* __restrict__ offs, int K, int64_t M,
+                                                           int chunk, int64_t per_k /* cin*cout */,
+                                                           float* __restrict__ gw, int accumulate) {
+  __shared__ float s_part[8][33];
   const int k = blockIdx.y;
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per_k) return;
+  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
   int64_t first = 0, count;
   if (!offs) {
     count = (M + chunk - 1) / chunk;
@@ -210,9 +213,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, const int64
     count = (offs[k + 1] - offs[k] + chunk - 1) / chunk;
   }
   float s = 0.f;
-  for (int64_t c = 0; c < count; ++c) s += slabs[(first + c) * per_k + e];
-  float* dst = gw + (int64_t)k * per_k + e;
-  *dst = accumulate ? *dst + s : s;
+  if (e < per_k)
+    for (int64_t c = cl; c < count; c += 8) s += slabs[(first + c) * per_k + e];
+  s_part[cl][el] = s;
+  __syncthreads();
+  if (cl == 0 && e < per_k) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += s_part[q][el];
+    float* dst = gw + (int64_t)k * per_k + e;
+    *dst = accumulate ? *dst + s : s;
+  }
 }
 
 // tiny-channel stem (cin = 3): slab[chunk][c][n] = sum_p x[i_p][c] * g[j_p][n]
@@ -274,13 +284,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[(int64_t)blockIdx.x * c + col] = s;
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nblocks, int c,
-                                    float* __restrict__ out, int accumulate) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblocks, int c,
+                                                           float* __restrict__ out, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per column
   if (col >= c) return;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * c + col];
-  out[col] = accumulate ? out[col] + s : s;
+  for (int b = lane; b < nblocks; b += 64) s += part[(int64_t)b * c + col];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d, 64);
+  if (lane == 0) out[col] = accumulate ? out[col] + s : s;
 }
 
 template <int CT>
@@ -401,7 +414,7 @@ int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
     }
     if (rc) return rc;
   }
-  wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per_k, 256), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
+  wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
                                                                                       per_k, gweight, accumulate);
   PCMI_LAUNCH_CHECK();
   if (gbias) {
@@ -410,7 +423,7 @@ int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
     const int rows_per_block = (int)ceil_div(n_out, nblocks);
     colsum_partial_kernel<<<nblocks, 256, 0, st>>>(gout, gout_ld, n_out, cout, rows_per_block, part);
     PCMI_LAUNCH_CHECK();
-    colsum_final_kernel<<<dim3((unsigned)ceil_div(cout, 256)), 256, 0, st>>>(part, nblocks, cout, gbias, accumulate);
+    colsum_final_kernel<<<dim3((unsigned)ceil_div(cout, 4)), 256, 0, st>>>(part, nblocks, cout, gbias, accumulate);
     PCMI_LAUNCH_CHECK();
   }
   return PCMI_OK;
