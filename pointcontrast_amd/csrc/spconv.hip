@@ -451,6 +451,12 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair) {
   p.ksplit = 1;
   p.RW = rows >= 96 ? 4 : (rows >= 48 ? 2 : 1);
   if (p.RW == 1 && p.NT > 2) p.NT = (nt_all % 2 == 0) ? 2 : 1;  // the cross-wave reduction lives in LDS
+  // small levels: narrow output slices partition the weights (no extra weight traffic) and multiply the
+  // number of resident workgroups; the re-gathered rows are L2-resident at these sizes
+  if (rows < 2048)
+    p.NT = 1;
+  else if (rows < 8192 && p.NT > 2)
+    p.NT = (nt_all % 2 == 0) ? 2 : 1;
   if (!pair && K > 1) {
     const int64_t wgs = ceil_div(rows, 32 * p.RW) * (nt_all / p.NT);
     const int64_t target = (5 * (int64_t)num_cu()) / 2;

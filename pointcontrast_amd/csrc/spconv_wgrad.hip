@@ -195,16 +195,20 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
   }
 }
 
-// gW[k][e] = sum over the chunks of offset k of slab[chunk][e].  32 elements x 8 chunk lanes per
-// workgroup: the chunk loop of one output is split 8 ways and folded through LDS in fixed order.
+// gW[k][e] = sum over the chunks of offset k of slab[chunk][e] (fixed order -> deterministic).
+// LANES == 1: one thread per output element (few chunks per offset: small levels).
+// LANES == 8: 32 elements x 8 chunk lanes per workgroup, folded through LDS (many chunks per offset:
+//             level 1, dense 1x1 convs), so the serial chain of dependent loads is 8x shorter.
+template <int LANES>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
                                                            const int64_t* __restrict__ offs, int K, int64_t M,
                                                            int chunk, int64_t per_k /* cin*cout */,
                                                            float* __restrict__ gw, int accumulate) {
-  __shared__ float s_part[8][33];
+  __shared__ float s_part[LANES][33];
   const int k = blockIdx.y;
-  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  constexpr int EPB = 256 / LANES;  // elements per block
+  const int el = threadIdx.x % EPB, cl = threadIdx.x / EPB;
+  const int64_t e = (int64_t)blockIdx.x * EPB + el;
   int64_t first = 0, count;
   if (!offs) {
     count = (M + chunk - 1) / chunk;
@@ -214,12 +218,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   float s = 0.f;
   if (e < per_k)
-    for (int64_t c = cl; c < count; c += 8) s += slabs[(first + c) * per_k + e];
-  s_part[cl][el] = s;
-  __syncthreads();
-  if (cl == 0 && e < per_k) {
+    for (int64_t c = cl; c < count; c += LANES) s += slabs[(first + c) * per_k + e];
+  if (LANES > 1) {
+    s_part[cl][el] = s;
+    __syncthreads();
+    if (cl != 0) return;
 #pragma unroll
-    for (int q = 1; q < 8; ++q) s += s_part[q][el];
+    for (int q = 1; q < LANES; ++q) s += s_part[q][el];
+  }
+  if (e < per_k) {
     float* dst = gw + (int64_t)k * per_k + e;
     *dst = accumulate ? *dst + s : s;
   }
@@ -414,8 +421,12 @@ int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
     }
     if (rc) return rc;
   }
-  wgrad_reduce_kernel<<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
-                                                                                      per_k, gweight, accumulate);
+  if (nchunks > 16 * (int64_t)K)
+    wgrad_reduce_kernel<8><<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
+                                                                                          per_k, gweight, accumulate);
+  else
+    wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(per_k, 256), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
+                                                                                           per_k, gweight, accumulate);
   PCMI_LAUNCH_CHECK();
   if (gbias) {
     float* part = (float*)((char*)ws + align_up(slab_bytes, 256));
