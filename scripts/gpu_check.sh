@@ -43,4 +43,16 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   find gpurun_out/prof -name "*kernel_stats*" | head
   find gpurun_out/prof -name "*kernel_trace*" -size +8M -delete
 fi
+if [ "${SKIP_PMC:-0}" != "1" ]; then
+  # HBM traffic / MFMA counters of the dominant kernels: counters in their own passes, kernel-trace only
+  cd /tmp
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE"; do
+    tag=$(echo $pass | cut -d" " -f1)
+    timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag" -o pmc -- python "$GRAFT_REPO_ROOT/scripts/pmc_probe.py" > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log" 2>&1
+    echo "pmc $tag exit: $?" >> "$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log"
+  done
+  cd "$GRAFT_REPO_ROOT"
+  find gpurun_out -name "*kernel_trace*" -size +8M -delete
+  ls gpurun_out/pmc_* | head -20
+fi
 echo done

@@ -1,0 +1,49 @@
+"""Runs the dominant kernels a few times each so that rocprofv3 --pmc passes can attribute HBM traffic
+(FETCH_SIZE / WRITE_SIZE) and MFMA activity to them.  The first kernels are a calibration pair with a
+known byte count in the same access width (float4 per lane): pcmi_add on 3 x 256 MiB buffers."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+import pointcontrast_amd.minkowski as ME
+from pointcontrast_amd._lib import lib, check
+from pointcontrast_amd.runtime import ptr, cur_stream, ws_args
+
+dev = torch.device("cuda:0")
+REP = 3
+# calibration: y = a + b, 2 x 256 MiB read + 256 MiB written per launch (well past the 256 MiB L3)
+n, c = 1 << 19, 128
+a, b, y = (torch.randn(n, c, device=dev) for _ in range(3))
+for _ in range(REP):
+  check(lib.pcmi_add(ptr(a), c, ptr(b), c, n, c, ptr(y), c, cur_stream(dev)))
+print("CAL eltwise_kernel<2> read_bytes=%d write_bytes=%d" % (2 * n * c * 4, n * c * 4))
+del a, b, y
+
+batch = bench.get_batch(0, 4, 0.025)
+st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(dev)
+cm, key = st.coords_man, st.coords_key
+m = cm.kernel_map(key, key, 3, 1, 3)
+N = st.F.shape[0]
+
+
+def conv(cin, cout, kmap, K, n_in, n_out):
+  W = torch.randn((K, cin, cout), device=dev) * 0.05
+  x, g = torch.randn(n_in, cin, device=dev), torch.randn(n_out, cout, device=dev)
+  yy, gin, gw = torch.empty(n_out, cout, device=dev), torch.empty(n_in, cin, device=dev), torch.empty_like(W)
+  ws, wsb = ws_args(lib.pcmi_spconv_workspace_bytes(n_in, n_out, cin, cout, K, kmap.M), dev)
+  s = cur_stream(dev)
+  for _ in range(REP):
+    check(lib.pcmi_spconv_fwd(ptr(x), cin, n_in, cin, ptr(W), cout, C.byref(kmap), 0, None, ptr(yy), cout, n_out, ws, wsb, s))
+    check(lib.pcmi_spconv_bwd_data(ptr(g), cout, n_out, cout, ptr(W), cin, C.byref(kmap), 0, ptr(gin), cin, n_in, ws, wsb, s))
+    check(lib.pcmi_spconv_bwd_weight(ptr(x), cin, n_in, cin, ptr(g), cout, n_out, cout, C.byref(kmap), 0, ptr(gw), None, ws, wsb, s))
+  M = kmap.M
+  print("ALGO conv %d->%d K=%d pairs=%d fwd_bytes=%d bwd_bytes=%d wgrad_bytes=%d flops=%d" %
+        (cin, cout, K, M, M * (4 * cin + 8) + n_out * 4 * cout + 4 * K * cin * cout,
+         M * (4 * cout + 8) + n_in * 4 * cin + 4 * K * cin * cout, M * 4 * (cin + cout) + 8 * M + 4 * K * cin * cout,
+         2 * M * cin * cout))
+
+
+conv(96, 96, m, 27, N, N)
+conv(32, 32, m, 27, N, N)
+torch.cuda.synchronize()
+print("done")
