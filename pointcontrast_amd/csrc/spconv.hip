@@ -36,6 +36,7 @@
 namespace pcmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));  // first-class vector: HIP's float4 struct went through scratch here
 
 constexpr int kKC = 32;  // contraction channels per staged weight chunk
 
@@ -62,8 +63,47 @@ struct ConvArgs {
   int accumulate;        // out += result instead of out = result (only when ksplit == 1)
 };
 
+// Weight chunk [32 x 32*NT] global -> registers -> LDS.  WT: B[c][n] = W[n][c] (backward-data).
+template <int NT, bool WT>
+__device__ __forceinline__ void load_b_regs(v4f (&breg)[NT], const float* __restrict__ wb, int64_t w_sc,
+                                            int64_t w_sn, int c0, int n0, int t) {
+  constexpr int NS = 32 * NT;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int e = t + i * 256;  // float4 index inside the chunk
+    if (!WT) {
+      const int c = e / (NS / 4), n4 = e % (NS / 4);
+      breg[i] = *reinterpret_cast<const v4f*>(wb + (int64_t)(c0 + c) * w_sc + n0 + n4 * 4);
+    } else {
+      const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+      breg[i] = *reinterpret_cast<const v4f*>(wb + (int64_t)(n0 + n) * w_sn + c0 + c4 * 4);
+    }
+  }
+}
+
+template <int NT, bool WT, int LDB>
+__device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT], float* __restrict__ sb, int t) {
+  constexpr int NS = 32 * NT;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int e = t + i * 256;
+    if (!WT) {
+      const int c = e / (NS / 4), n4 = e % (NS / 4);
+      *reinterpret_cast<v4f*>(sb + c * LDB + n4 * 4) = breg[i];
+    } else {
+      const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+      sb[(c4 * 4 + 0) * LDB + n] = breg[i].x;
+      sb[(c4 * 4 + 1) * LDB + n] = breg[i].y;
+      sb[(c4 * 4 + 2) * LDB + n] = breg[i].z;
+      sb[(c4 * 4 + 3) * LDB + n] = breg[i].w;
+    }
+  }
+}
+
 template <int NT, int RW, bool WT, bool PAIR, int DEPTH>
-__global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
+// min 3 waves/SIMD: with this bound hipcc keeps the accumulators in plain VGPRs (<= 158 in total, no scratch);
+// without it it split them into AGPRs at 170-220 registers total and 2 waves/SIMD
+__global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   constexpr int TM = 32 * RW;        // rows per workgroup tile
   constexpr int KG = 4 / RW;         // wave groups splitting the contraction blocks
   constexpr int BPG = 4 / KG;        // eight-channel blocks per wave group per chunk
@@ -158,46 +198,16 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(ConvArgs a) {
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   // ---- staging helpers -------------------------------------------------------------------
-  constexpr int NB4 = (kKC * NS / 4 + 255) / 256;  // float4 loads per thread per chunk
-  float4 breg[NB4];
+  // (kKC * NS / 4 = 256 * NT float4 per chunk -> exactly NT per thread; kept in registers: the loops
+  //  below are fully unrolled over a by-reference array, a lambda capture of it went to scratch)
+  v4f breg[NT];
   auto load_b = [&](int step) {
     const int kslot = s_klist[step / nch];
     const int c0 = (step % nch) * kKC;
     const int wk = PAIR ? a.wsel[k_single] : a.wsel[kbeg_blk + kslot];
-    const float* wb = a.w + (int64_t)wk * a.w_kstride;
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-      const int e = t + i * 256;  // float4 index inside the chunk
-      if (kKC * NS / 4 % 256 == 0 || e < kKC * NS / 4) {
-        if (!WT) {
-          const int c = e / (NS / 4), n4 = e % (NS / 4);
-          breg[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(c0 + c) * a.w_sc + n0 + n4 * 4);
-        } else {
-          const int n = e / (kKC / 4), c4 = e % (kKC / 4);
-          breg[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(n0 + n) * a.w_sn + c0 + c4 * 4);
-        }
-      }
-    }
+    load_b_regs<NT, WT>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
   };
-  auto store_b = [&](int buf) {
-    float* sb = s_f + buf * (kKC * LDB);
-#pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-      const int e = t + i * 256;
-      if (kKC * NS / 4 % 256 == 0 || e < kKC * NS / 4) {
-        if (!WT) {
-          const int c = e / (NS / 4), n4 = e % (NS / 4);
-          *reinterpret_cast<float4*>(sb + c * LDB + n4 * 4) = breg[i];
-        } else {
-          const int n = e / (kKC / 4), c4 = e % (kKC / 4);
-          sb[(c4 * 4 + 0) * LDB + n] = breg[i].x;
-          sb[(c4 * 4 + 1) * LDB + n] = breg[i].y;
-          sb[(c4 * 4 + 2) * LDB + n] = breg[i].z;
-          sb[(c4 * 4 + 3) * LDB + n] = breg[i].w;
-        }
-      }
-    }
-  };
+  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
   // A operands live in a three-deep register ring (gathers are the long-latency loads: HBM / far-L2
   // misses), B chunks are one step ahead through LDS (weights are L2 hits shared by every workgroup).
   float4 a0[BPG], a1[BPG], a2[BPG];
@@ -404,8 +414,8 @@ static int launch_nt(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   switch (NT) {
     case 1: return launch_one<1, RW, WT, PAIR>(a, grid, st);
     case 2: return launch_one<2, RW, WT, PAIR>(a, grid, st);
-    case 3: return launch_one<3, RW, WT, PAIR>(a, grid, st);
-    case 4: return launch_one<4, RW, WT, PAIR>(a, grid, st);
+    case 3: if constexpr (RW > 1) return launch_one<3, RW, WT, PAIR>(a, grid, st); else break;
+    case 4: if constexpr (RW > 1) return launch_one<4, RW, WT, PAIR>(a, grid, st); else break;
   }
   set_error("spconv: bad NT %d", NT);
   return PCMI_ERR_INVALID;

@@ -92,7 +92,8 @@ __device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int c
 }
 
 template <int CT, int NT>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs a) {
+// min 2 waves/SIMD keeps the 9 accumulator tiles in VGPRs (198 registers); unbounded, hipcc used 190 + 144 AGPRs = 1 wave/SIMD
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   __shared__ float s_red[32 * CT][32 * NT + 1];
   __shared__ int64_t s_desc[3];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
