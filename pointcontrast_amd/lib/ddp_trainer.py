@@ -141,13 +141,40 @@ class ContrastiveLossTrainer:
     return out.view(idx_cpu.shape)
 
   # -- shared pieces of one iteration ----------------------------------------------------------
-  def _forward_pair(self, input_dict):
+  # A batch is *prepared* (uploads, coordinate hash / levels / kernel maps on the plan stream, host-side index
+  # selection) independently of the network state, so with misc.prefetch the next batch is prepared right after
+  # the current step has been enqueued and overlaps with the GPU still working on it.
+  def _prepare(self, input_dict, draws=None):
     s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device)
-    if self.engine is None:
-      F0 = self.model(s0).F
-      s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
-      return F0, self.model(s1).F
     s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
+    if self.engine is not None:
+      s0.coords_man.plan_unet(self.engine.n_down)
+      s1.coords_man.plan_unet(self.engine.n_down)
+    prep = {"input": input_dict, "s0": s0, "s1": s1}
+    self._prepare_loss(prep, draws)
+    return prep
+
+  def _prepare_loss(self, prep, draws):
+    pass
+
+  def _next_prepared(self, data_loader_iter, data_timer, draws):
+    nxt = getattr(self, "_prefetched", None)
+    self._prefetched = None
+    if nxt is not None and draws is None:
+      return nxt, 0.0
+    data_timer.tic()
+    input_dict = next(data_loader_iter)
+    data_time = data_timer.toc(average=False)
+    return self._prepare(input_dict, draws), data_time
+
+  def _prefetch(self, data_loader_iter, draws):
+    if draws is None and self.config.misc.get("prefetch", True):
+      self._prefetched = self._prepare(next(data_loader_iter))
+
+  def _forward_pair(self, prep):
+    s0, s1 = prep["s0"], prep["s1"]
+    if self.engine is None:
+      return self.model(s0).F, self.model(s1).F
     F0 = self.engine.forward(0, s0, self.model.training).requires_grad_(True)
     F1 = self.engine.forward(1, s1, self.model.training).requires_grad_(True)
     self._feats = (F0, F1)
@@ -235,17 +262,16 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
     data_meter, data_timer, total_timer = timers
     self.optimizer.zero_grad()
     total_timer.tic()
-    data_timer.tic()
-    input_dict = next(data_loader_iter)
-    data_time = data_timer.toc(average=False)
-    F0, F1 = self._forward_pair(input_dict)
+    prep, data_time = self._next_prepared(data_loader_iter, data_timer, draws)
+    F0, F1 = self._forward_pair(prep)
     pos_loss, neg_loss = self.contrastive_hardest_negative_loss(
-        F0, F1, input_dict["correspondences"],
+        F0, F1, prep["input"]["correspondences"],
         num_pos=self.config.trainer.num_pos_per_batch * self.batch_size,
         num_hn_samples=self.config.trainer.num_hn_samples_per_batch * self.batch_size, draws=draws)
     loss = pos_loss + neg_loss
     result = self._backward_and_step(loss, {"loss": loss.detach(), "pos_loss": pos_loss.detach(),
                                             "neg_loss": neg_loss.detach()})
+    self._prefetch(data_loader_iter, draws)
     total_timer.toc()
     data_meter.update(data_time)
     return result
@@ -285,20 +311,24 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
       q_unique, k_sel = q_unique[si], k_sel[si]
     return q_unique, k_sel
 
+  def _prepare_loss(self, prep, draws):
+    q_idx, k_idx = self.select_pairs(prep["input"]["correspondences"], self.npos, draws)
+    slot = getattr(self, "_slot", 0)
+    self._slot = slot ^ 2  # two staging buffer pairs: the prefetched batch must not overwrite the live one
+    prep["q_idx"], prep["k_idx"] = self._upload(q_idx, slot), self._upload(k_idx, slot + 1)
+
   def _train_iter(self, data_loader_iter, timers, draws=None):
     self.model.train()
     data_meter, data_timer, total_timer = timers
     self.optimizer.zero_grad()
     total_timer.tic()
-    data_timer.tic()
-    input_dict = next(data_loader_iter)
-    data_time = data_timer.toc(average=False)
-    F0, F1 = self._forward_pair(input_dict)
-    q_idx, k_idx = self.select_pairs(input_dict["correspondences"], self.npos, draws)
-    q = PF.GatherRowsFunction.apply(F0, self._upload(q_idx, 0))
-    k = PF.GatherRowsFunction.apply(F1, self._upload(k_idx, 1))
+    prep, data_time = self._next_prepared(data_loader_iter, data_timer, draws)
+    F0, F1 = self._forward_pair(prep)
+    q = PF.GatherRowsFunction.apply(F0, prep["q_idx"])
+    k = PF.GatherRowsFunction.apply(F1, prep["k_idx"])
     loss = PF.NCELossFunction.apply(q, k, self.T)
     result = self._backward_and_step(loss, {"loss": loss.detach()})
+    self._prefetch(data_loader_iter, draws)
     total_timer.toc()
     data_meter.update(data_time)
     return result
