@@ -113,6 +113,11 @@ typedef struct pcmi_kmap {
   const int64_t* offs;     /* [K+1] device prefix of the group sizes */
   int64_t offs_host[PCMI_MAX_KERNEL_VOLUME + 1];
   int32_t mirror[PCMI_MAX_KERNEL_VOLUME]; /* offset_{mirror[k]} == -offset_k (stride 1) */
+  /* Processing order for the conv kernels (stride-1 maps of large levels, else NULL): rows sorted by their
+   * 27-bit neighbour-occupancy mask so that a 32-row wave group shares its set of occupied offsets.
+   * perm[i] = row handled at position i; nbr_perm[k][i] = nbr[k][perm[i]].  Results are unaffected. */
+  const int32_t* perm;
+  const int32_t* nbr_perm;
 } pcmi_kmap_t;
 
 /* Host-side enumeration of the kernel offsets in weight-slice order

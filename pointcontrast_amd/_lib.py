@@ -32,6 +32,7 @@ class KMap(C.Structure):
       ("n_in", c_i64), ("n_out", c_i64), ("M", c_i64),
       ("nbr", c_vp), ("pair_in", c_vp), ("pair_out", c_vp), ("offs", c_vp),
       ("offs_host", c_i64 * (MAX_K + 1)), ("mirror", c_i32 * MAX_K),
+      ("perm", c_vp), ("nbr_perm", c_vp),
   ]
 
 

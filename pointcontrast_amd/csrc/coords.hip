@@ -14,7 +14,7 @@
 #include <cstring>
 #include <vector>
 
-#include "common.h"
+#include "internal.h"
 
 namespace pcmi {
 
@@ -311,7 +311,8 @@ struct OffsetTable {
   int8_t o[PCMI_MAX_KERNEL_VOLUME][3];
 };
 
-constexpr int kMapTile = 128;  // rows per tile == rows per spconv workgroup tile
+constexpr int kMapTile = 128;
+constexpr int64_t kSortRowsMin = 4096;  // levels below this are latency-, not MFMA-bound: no sorted order  // rows per tile == rows per spconv workgroup tile
 
 // 3^3 / stride-1 map.  One workgroup = one 128-row tile: the tile's coordinates are staged in
 // LDS once, the 27*128 probes are spread over the 256 threads (consecutive threads take the
@@ -692,6 +693,22 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
     PCMI_HIP_CHECK(hipMemsetAsync(offs, 0, sizeof(int64_t) * (K + 1), st));
   }
   m.M = m.offs_host[K];
+  m.perm = nullptr;
+  m.nbr_perm = nullptr;
+  if (stride == 1 && n_out >= kSortRowsMin) {
+    int32_t* perm = h->persistent.alloc_n<int32_t>(n_out);
+    int32_t* nbr_perm = h->persistent.alloc_n<int32_t>(tot);
+    uint32_t* mk_in = h->scratch.alloc_n<uint32_t>(n_out);
+    uint32_t* mk_out = h->scratch.alloc_n<uint32_t>(n_out);
+    int32_t* iota = h->scratch.alloc_n<int32_t>(n_out);
+    const size_t tb = sort_rows_temp_bytes(n_out);
+    void* temp = h->scratch.alloc(tb);
+    if (!perm || !nbr_perm || !mk_in || !mk_out || !iota || !temp) return PCMI_ERR_HIP;
+    rc = sort_rows_by_mask(nbr, K, n_out, mk_in, mk_out, iota, temp, tb, perm, nbr_perm, st);
+    if (rc) return rc;
+    m.perm = perm;
+    m.nbr_perm = nbr_perm;
+  }
   m.nbr = nbr;
   m.pair_in = pair_in;
   m.pair_out = pair_out;

@@ -18,4 +18,8 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
                 int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,
                 float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
 
+size_t sort_rows_temp_bytes(int64_t n);
+int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, uint32_t* mask_in, uint32_t* mask_out, int32_t* iota,
+                      void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st);
+
 }  // namespace pcmi

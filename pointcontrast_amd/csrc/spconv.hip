@@ -48,7 +48,8 @@ struct ConvArgs {
   int64_t w_kstride;     // floats per weight slice (cin*cout)
   int64_t w_sc, w_sn;    // B_k[c][n] = w[wk*w_kstride + c*w_sc + n*w_sn]
   int N;                 // output channels (multiple of 32)
-  const int32_t* nbr;    // [K][n_rows] or nullptr (identity)
+  const int32_t* nbr;    // [K][n_rows] or nullptr (identity); the permuted table when perm is set
+  const int32_t* perm;   // nullable: tile position -> output row (mask-sorted processing order)
   const int32_t* pair_src;  // pair mode: gather row per pair
   const int32_t* pair_dst;  // pair mode: output row per pair
   const int64_t* offs;   // pair mode: [K+1] device group offsets
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
     const int64_t row0 = (int64_t)blockIdx.x * TM;
     const int kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
     const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
-    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (int32_t)(row0 + t) : -1;
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
     for (int p = t; p < (kend - kbeg) * TM; p += 256) {
       const int kk = p / TM, rr = p - kk * TM;
       const int64_t row = row0 + rr;
@@ -511,6 +512,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   a.n_rows = n_rows;
   a.bias = bias;
   a.nbr = nullptr;
+  a.perm = nullptr;
   a.pair_src = a.pair_dst = nullptr;
   a.offs = nullptr;
   a.ksplit = 1;
@@ -532,6 +534,10 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
                         : launch_rw<false, true>(p.RW, p.NT, a, grid, st);
   }
   a.nbr = map ? map->nbr : nullptr;
+  if (map && map->perm && map->nbr_perm) {  // same results, rows visited in mask-sorted order
+    a.nbr = map->nbr_perm;
+    a.perm = map->perm;
+  }
   Plan p = make_plan(n_rows, N, a.K, false);
   if (p.ksplit > 1) {
     const size_t need = (size_t)p.ksplit * n_rows * N * sizeof(float);
