@@ -308,8 +308,17 @@ def main():
     if not args.no_roofline:
       dom, kernels = kernel_rooflines(batch, device)
       log("rooflines done")
+      # HBM-side bytes per launch of the same kernel / shape from the separate rocprofv3 --pmc passes
+      # (scripts/pmc_probe.py -> scripts/pmc_summary.py -> profiles/pmc_traffic.json); null if never collected
+      traffic = None
+      try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+          traffic = json.load(f)["bytes_per_launch"].get("spconv_mfma_kernel<3, 4, false, false, 2>")
+      except (OSError, ValueError, KeyError):
+        pass
       out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                         "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"], "ms": dom["ms"]}
+                         "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (PMC, calibrated)",
+                         "kernel": dom["kernel"], "ms": dom["ms"]}
       out["kernels"] = kernels
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = run_cpu_baseline_bounded()

@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a
 // launch, one workgroup per float4 channel column.  Replaces three launches (partial, final, apply) whose
 // run time at these sizes is pure launch latency; used by 44 of the 62 BatchNorms of Res16UNet34C.
 constexpr int64_t kSmallRows = 8192;
+constexpr int kSmallThreads = 1024;  // 16 waves per channel column: the two passes are latency-, not bandwidth-bound
 
 __device__ inline void chan_merge(float& n, float4& mean, float4& m2, float on, const float4& omean, const float4& om2) {
   const float tot = n + on;
@@ -322,19 +323,19 @@ __device__ inline void chan_merge(float& n, float4& mean, float4& m2, float on, 
   n = tot;
 }
 
-__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t n,
+__global__ __launch_bounds__(kSmallThreads) void bn_small_fwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t n,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float momentum, float eps, const float* __restrict__ res,
                                                            int64_t res_ld, int relu, float* __restrict__ y, int64_t y_ld,
                                                            float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  __shared__ float s_n[256];
-  __shared__ float4 s_mean[256];
-  __shared__ float4 s_m2[256];
+  __shared__ float s_n[kSmallThreads];
+  __shared__ float4 s_mean[kSmallThreads];
+  __shared__ float4 s_m2[kSmallThreads];
   const int t = threadIdx.x, col = blockIdx.x;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
   float cnt = 0.f;
-  for (int64_t r = t; r < n; r += 256) {
+  for (int64_t r = t; r < n; r += kSmallThreads) {
     const float4 v = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
     sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
     sq.x = fmaf(v.x, v.x, sq.x); sq.y = fmaf(v.y, v.y, sq.y); sq.z = fmaf(v.z, v.z, sq.z); sq.w = fmaf(v.w, v.w, sq.w);
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
   }
   s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
   __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
+  for (int d = kSmallThreads / 2; d >= 1; d >>= 1) {
     if (t < d) {
       chan_merge(cnt, mean, m2, s_n[t + d], s_mean[t + d], s_m2[t + d]);
       s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     }
   }
   const float4 g = reinterpret_cast<const float4*>(gamma)[col], b = reinterpret_cast<const float4*>(beta)[col];
-  for (int64_t r = t; r < n; r += 256) {
+  for (int64_t r = t; r < n; r += kSmallThreads) {
     const float4 v = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
     float4 o = make_float4((v.x - mean.x) * is.x * g.x + b.x, (v.y - mean.y) * is.y * g.y + b.y,
                            (v.z - mean.z) * is.z * g.z + b.z, (v.w - mean.w) * is.w * g.w + b.w);
@@ -388,18 +389,18 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void bn_small_bwd_kernel(
+__global__ __launch_bounds__(kSmallThreads) void bn_small_bwd_kernel(
     const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t x_ld,
     const float* __restrict__ ymask, int64_t y_ld, int64_t n, const float* __restrict__ gamma,
     const float* __restrict__ mean_p, const float* __restrict__ invstd_p, float* __restrict__ dx, int64_t dx_ld,
     float* __restrict__ dres, int64_t dres_ld, int dres_accumulate, float* __restrict__ dgamma,
     float* __restrict__ dbeta, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
-  __shared__ float4 s_a[256];
-  __shared__ float4 s_b[256];
+  __shared__ float4 s_a[kSmallThreads];
+  __shared__ float4 s_b[kSmallThreads];
   const int t = threadIdx.x, col = blockIdx.x;
   const float4 mu = reinterpret_cast<const float4*>(mean_p)[col], is = reinterpret_cast<const float4*>(invstd_p)[col];
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-  for (int64_t r = t; r < n; r += 256) {
+  for (int64_t r = t; r < n; r += kSmallThreads) {
     float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
     if (ymask) {
       const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(
   }
   s_a[t] = a; s_b[t] = b;
   __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
+  for (int d = kSmallThreads / 2; d >= 1; d >>= 1) {
     if (t < d) {
       const float4 oa = s_a[t + d], ob = s_b[t + d];
       a = make_float4(a.x + oa.x, a.y + oa.y, a.z + oa.z, a.w + oa.w);
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(
   }
   const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
   const float inv_n = 1.0f / (float)n;
-  for (int64_t r = t; r < n; r += 256) {
+  for (int64_t r = t; r < n; r += kSmallThreads) {
     float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
     if (ymask) {
       const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
@@ -491,7 +492,7 @@ int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const floa
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_fwd_train: workspace too small");
   hipStream_t st = as_stream(stream);
   if (n <= kSmallRows) {
-    bn_small_fwd_kernel<<<c / 4, 256, 0, st>>>(x, x_ld, n, gamma, beta, running_mean, running_var, momentum, eps, residual, res_ld,
+    bn_small_fwd_kernel<<<c / 4, kSmallThreads, 0, st>>>(x, x_ld, n, gamma, beta, running_mean, running_var, momentum, eps, residual, res_ld,
                                                relu, y, y_ld, save_mean, save_invstd);
     PCMI_LAUNCH_CHECK();
     return PCMI_OK;
@@ -544,7 +545,7 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   PCMI_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && n > 0, PCMI_ERR_INVALID, "bn_bwd: bad argument");
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_bwd: workspace too small");
   if (n <= kSmallRows) {
-    bn_small_bwd_kernel<<<c / 4, 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, gamma, save_mean, save_invstd, dx, dx_ld,
+    bn_small_bwd_kernel<<<c / 4, kSmallThreads, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, gamma, save_mean, save_invstd, dx, dx_ld,
                                                dres, dres_ld, dres_accumulate, dgamma, dbeta, acc_dgamma, acc_dbeta);
     PCMI_LAUNCH_CHECK();
     return PCMI_OK;

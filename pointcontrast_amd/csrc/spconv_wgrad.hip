@@ -48,12 +48,14 @@ struct VecLoad<2> {
     v[1] = t.y;
   }
 };
+typedef float v3f_unaligned __attribute__((ext_vector_type(3), aligned(4)));
 template <>
 struct VecLoad<3> {
-  static __device__ inline void ld(const float* p, float* v) {
-    v[0] = p[0];
-    v[1] = p[1];
-    v[2] = p[2];
+  static __device__ inline void ld(const float* p, float* v) {  // one global_load_dwordx3 (dword aligned)
+    const v3f_unaligned t = *reinterpret_cast<const v3f_unaligned*>(p);
+    v[0] = t.x;
+    v[1] = t.y;
+    v[2] = t.z;
   }
 };
 template <>

@@ -1,0 +1,63 @@
+"""Turns the rocprofv3 --pmc passes of scripts/pmc_probe.py (gpurun_out/pmc_*/pmc_counter_collection.csv) into
+profiles/<tag>_pmc_summary.md and profiles/pmc_traffic.json (HBM-side bytes per launch of the dominant kernels).
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of a 16-byte-per-lane read stream
+(MI355X_MICROARCH.md "HBM"), so both are calibrated on the first kernel of the probe (eltwise add, known bytes)
+before being applied to the conv kernels, whose loads are float4 per lane as well."""
+import collections, csv, json, os, re, sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+
+
+def load(name):
+  d = collections.defaultdict(lambda: collections.defaultdict(list))
+  path = os.path.join(src, "pmc_%s" % name, "pmc_counter_collection.csv")
+  for r in csv.DictReader(open(path)):
+    k = re.sub(r"void |pcmi::", "", r["Kernel_Name"])
+    d[k][r["Counter_Name"]].append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3))
+  return d
+
+
+def mean(xs):
+  return sum(x[0] for x in xs) / len(xs)
+
+
+F, W, M = load("FETCH_SIZE"), load("WRITE_SIZE"), load("SQ_VALU_MFMA_BUSY_CYCLES")
+cal = [k for k in F if k.startswith("eltwise_kernel<2>")][0]
+cal_read, cal_write = 2 * (1 << 19) * 128 * 4, (1 << 19) * 128 * 4
+f_scale = cal_read / (mean(F[cal]["FETCH_SIZE"]) * 1024)
+w_scale = cal_write / (mean(W[cal]["WRITE_SIZE"]) * 1024)
+algo = {}
+for line in open(os.path.join(src, "pmc_FETCH_SIZE.log")):
+  if line.startswith("ALGO"):
+    m = dict(kv.split("=") for kv in line.split()[3:])
+    algo[line.split()[2]] = {k: int(v) for k, v in m.items()}
+rows, traffic = [], {}
+for k in F:
+  if not any(x in k for x in ("spconv_mfma", "wgrad_mfma", "eltwise_kernel<2>")):
+    continue
+  rd = mean(F[k]["FETCH_SIZE"]) * 1024 * f_scale
+  wr = mean(W[k]["WRITE_SIZE"]) * 1024 * w_scale if k in W else float("nan")
+  us = sum(x[1] for x in F[k]["FETCH_SIZE"]) / len(F[k]["FETCH_SIZE"])
+  util = mops = float("nan")
+  if k in M and "SQ_VALU_MFMA_BUSY_CYCLES" in M[k]:
+    gui = mean(M[k]["GRBM_GUI_ACTIVE"]) / 8.0  # summed over the 8 XCDs
+    util = mean(M[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / gui  # per SIMD (256 CUs x 4)
+    mops = mean(M[k]["SQ_INSTS_VALU_MFMA_MOPS_F32"]) * 512 * 1e-9
+  rows.append((k.split("(")[0], len(F[k]["FETCH_SIZE"]), us, rd * 1e-6, wr * 1e-6, util, mops))
+  traffic[k.split("(")[0]] = rd + wr
+md = ["# PMC summary (%s): rocprofv3 --kernel-trace --pmc <counter> -- python scripts/pmc_probe.py" % tag, "",
+      "calibration kernel `eltwise_kernel<2>` (536.9 MB read, 268.4 MB written, float4 per lane): FETCH_SIZE x %.3f, WRITE_SIZE x %.3f"
+      % (f_scale, w_scale), "",
+      "algorithmic bytes of the probed convs (SURVEY 8d formulae): " + json.dumps(algo), "",
+      "| kernel | launches | avg us (under counters) | read MB | written MB | MFMA busy (per SIMD) | issued GFLOP |", "|---|---|---|---|---|---|---|"]
+for r in rows:
+  md.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f %% | %.2f |" % (r[0], r[1], r[2], r[3], r[4], 100 * r[5], r[6]))
+md += ["", "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); issued GFLOP = "
+       "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 (compare with the algorithmic 2*M*Cin*Cout: the excess is MFMA work on absent neighbours)."]
+open(os.path.join(root, "profiles", "%s_pmc_summary.md" % tag), "w").write("\n".join(md) + "\n")
+json.dump({"source": "%s_pmc_summary.md" % tag, "bytes_per_launch": traffic, "algorithmic": algo},
+          open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print("\n".join(md))
