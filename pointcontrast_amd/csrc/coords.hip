@@ -704,7 +704,7 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
     const size_t tb = sort_rows_temp_bytes(n_out);
     void* temp = h->scratch.alloc(tb);
     if (!perm || !nbr_perm || !mk_in || !mk_out || !iota || !temp) return PCMI_ERR_HIP;
-    rc = sort_rows_by_mask(nbr, K, n_out, mk_in, mk_out, iota, temp, tb, perm, nbr_perm, st);
+    rc = sort_rows_by_mask(nbr, K, n_out, xcd_chunk_rows(n_out), mk_in, mk_out, iota, temp, tb, perm, nbr_perm, st);
     if (rc) return rc;
     m.perm = perm;
     m.nbr_perm = nbr_perm;

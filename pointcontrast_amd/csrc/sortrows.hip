@@ -13,13 +13,16 @@
 
 namespace pcmi {
 
-__global__ void row_mask_kernel(const int32_t* __restrict__ nbr, int K, int64_t n, uint32_t* __restrict__ mask,
-                                int32_t* __restrict__ iota) {
+// key = (spatial chunk << K) | occupancy mask: rows are sorted by mask only INSIDE the contiguous row range that
+// one XCD processes (see the tile swizzle in spconv.hip), so the loader's scan-order locality -- 98 % of the
+// gathers of a 1/8 chunk stay inside that chunk -- keeps working for that XCD's L2.
+__global__ void row_mask_kernel(const int32_t* __restrict__ nbr, int K, int64_t n, int64_t chunk_rows,
+                                uint32_t* __restrict__ mask, int32_t* __restrict__ iota) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   uint32_t m = 0;
   for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * n + j] >= 0 ? 1u : 0u) << k;
-  mask[j] = m;
+  mask[j] = m | ((uint32_t)(j / chunk_rows) << K);
   iota[j] = (int32_t)j;
 }
 
@@ -34,17 +37,18 @@ __global__ void permute_table_kernel(const int32_t* __restrict__ nbr, int K, int
 size_t sort_rows_temp_bytes(int64_t n) {
   size_t bytes = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, 27, (hipStream_t)0);
+                                           (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, 30, (hipStream_t)0);
   return bytes + 256;
 }
 
 // scratch: mask_in[n], mask_out[n] (uint32), iota[n] (int32), temp (sort_rows_temp_bytes(n))
-int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, uint32_t* mask_in, uint32_t* mask_out, int32_t* iota,
-                      void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st) {
+int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, uint32_t* mask_in, uint32_t* mask_out,
+                      int32_t* iota, void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st) {
   if (n == 0) return PCMI_OK;
-  row_mask_kernel<<<dim3((unsigned)ceil_div(n, 256)), 256, 0, st>>>(nbr, K, n, mask_in, iota);
+  PCMI_REQUIRE(K <= 27 && ceil_div(n, chunk_rows) <= 8, PCMI_ERR_INVALID, "sort_rows: key does not fit 30 bits");
+  row_mask_kernel<<<dim3((unsigned)ceil_div(n, 256)), 256, 0, st>>>(nbr, K, n, chunk_rows, mask_in, iota);
   PCMI_LAUNCH_CHECK();
-  PCMI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, mask_in, mask_out, iota, perm, (int)n, 0, K, st));
+  PCMI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, mask_in, mask_out, iota, perm, (int)n, 0, K + 3, st));
   permute_table_kernel<<<dim3((unsigned)ceil_div((int64_t)K * n, 256)), 256, 0, st>>>(nbr, K, n, perm, nbr_perm);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;

@@ -61,6 +61,7 @@ struct ConvArgs {
   int64_t split_stride;  // floats between partial buffers
   int ksplit;            // offsets are divided into ksplit contiguous ranges over blockIdx.z
   const float* bias;     // nullable, only when ksplit == 1
+  int xcd_tiles;         // > 0: tiles per XCD of the XCD-contiguous tile order (grid.x = 8 * xcd_tiles)
   int accumulate;        // out += result instead of out = result (only when ksplit == 1)
 };
 
@@ -160,7 +161,14 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
       s_nk = 1;
     }
   } else {
-    const int64_t row0 = (int64_t)blockIdx.x * TM;
+    // Workgroup b is observed to run on XCD b % 8 (never relied upon for correctness): give every XCD a
+    // CONTIGUOUS range of tiles, so that the rows its tiles gather (scan-order neighbours) share one L2.
+    int64_t tile = blockIdx.x;
+    if (a.xcd_tiles > 0) {
+      tile = (int64_t)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
+      if (tile * TM >= a.n_rows) return;
+    }
+    const int64_t row0 = tile * TM;
     const int kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
     const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
     if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
@@ -402,7 +410,7 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   // measured on the 96->96 level-1 conv: depth 3 wins with transposed weights (0.49 vs 0.61 ms), depth 2
   // (one more resident wave per SIMD) without (0.48 vs 0.64 ms)
   const int d = prefetch_depth(RW);
-  if (d == 3 || (d == 0 && WT))
+  if (d == 3)  // default depth 2: with the accumulators in VGPRs (launch bounds) depth 3 measured no gain
     spconv_mfma_kernel<NT, RW, WT, PAIR, 3><<<grid, 256, 0, st>>>(a);
   else
     spconv_mfma_kernel<NT, RW, WT, PAIR, 2><<<grid, 256, 0, st>>>(a);
@@ -517,6 +525,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   a.offs = nullptr;
   a.ksplit = 1;
   a.split_stride = 0;
+  a.xcd_tiles = 0;
   a.accumulate = accumulate;
   a.out = out;
   a.out_ld = out_ld;
@@ -549,7 +558,12 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
     a.bias = nullptr;
     a.accumulate = 0;
   }
-  dim3 grid((unsigned)ceil_div(n_rows, 32 * p.RW), (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
+  int64_t tiles = ceil_div(n_rows, 32 * p.RW);
+  if (tiles >= 64) {  // XCD-contiguous tile order (for RW == 4 it coincides with the chunks of the mask sort)
+    a.xcd_tiles = (int)ceil_div(tiles, 8);
+    tiles = (int64_t)a.xcd_tiles * 8;
+  }
+  dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
   int rc = w_transposed ? launch_rw<true, false>(p.RW, p.NT, a, grid, st)
                         : launch_rw<false, false>(p.RW, p.NT, a, grid, st);
   if (rc) return rc;
