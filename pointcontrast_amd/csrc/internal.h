@@ -24,4 +24,16 @@ int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, 
 // rows of the contiguous tile range one XCD processes (tile swizzle of the conv kernel, 128-row tiles)
 static inline int64_t xcd_chunk_rows(int64_t n) { return ceil_div(ceil_div(n, 128), 8) * 128; }
 
+// compute units of the current device (cached; 256 on MI355X)
+static inline int num_cu() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 }  // namespace pcmi

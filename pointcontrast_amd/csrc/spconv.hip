@@ -32,6 +32,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "internal.h"
 
 namespace pcmi {
 
@@ -253,17 +254,33 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
         if (more) v1 = load_a(step + 1, a1);
       }
       if (v0) {
-        const float* sb = s_f + (step & 1) * (kKC * LDB) + r;
+        // B fragments are read from LDS PF contraction steps AHEAD of the MFMAs that use them (register ring).
+        // Written inline, hipcc emitted ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, i.e. the full LDS latency in
+        // front of every 128 cycles of matrix work: SQ_VALU_MFMA_BUSY_CYCLES showed the pipe 52 % busy.  The
+        // sched_barriers pin the order (the scheduler otherwise sinks every read next to its use again).
+        const float* sb = s_f + (step & 1) * (kKC * LDB) + r + (8 * (kg * BPG) + 4 * h) * LDB;
+        constexpr int QN = 4 * BPG;                                // contraction steps of this wave per chunk
+        constexpr int PF0 = NT >= 3 ? 3 : (NT == 2 ? 4 : 6);       // >= ~380 cycles (6 MFMAs) between read and use
+        constexpr int PF = PF0 < QN ? PF0 : QN;
+        float bf[PF][NT];
 #pragma unroll
-        for (int b = 0; b < BPG; ++b) {
-          const float av[4] = {a0[b].x, a0[b].y, a0[b].z, a0[b].w};
+        for (int q = 0; q < PF; ++q)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const float* brow = sb + (8 * (kg * BPG + b) + 4 * h + s) * LDB;
+          for (int nt = 0; nt < NT; ++nt) bf[q][nt] = sb[(8 * (q >> 2) + (q & 3)) * LDB + nt * 32];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], brow[nt * 32], acc[nt], 0, 0, 0);
+        for (int q = 0; q < QN; ++q) {
+          const float4 ab = a0[q >> 2];
+          const float av = (q & 3) == 0 ? ab.x : (q & 3) == 1 ? ab.y : (q & 3) == 2 ? ab.z : ab.w;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[q % PF][nt], acc[nt], 0, 0, 0);
+          if (q + PF < QN) {
+            const int qq = q + PF;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[q % PF][nt] = sb[(8 * (qq >> 2) + (qq & 3)) * LDB + nt * 32];
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (more) store_b((step + 1) & 1);
@@ -445,18 +462,6 @@ struct Plan {
   int RW, NT, ksplit;
 };
 constexpr int kMaxKSplit = 27;
-
-static int g_num_cu = 0;
-static int num_cu() {
-  if (g_num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_num_cu = prop.multiProcessorCount;
-    if (g_num_cu <= 0) g_num_cu = 256;
-  }
-  return g_num_cu;
-}
 
 // rows: output rows (or pairs in pair mode); N: output channels; K: offsets.
 // Row tiles stay as large as the row count allows (a tile streams its weight slice once, so small

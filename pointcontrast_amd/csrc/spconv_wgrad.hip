@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "internal.h"
 
 namespace pcmi {
 
@@ -93,7 +94,7 @@ __device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int c
   *pb = *pe = 0;
 }
 
-template <int CT, int NT>
+template <int CT, int NT, bool IDX>
 // min 2 waves/SIMD keeps the 9 accumulator tiles in VGPRs (198 registers); unbounded, hipcc used 190 + 144 AGPRs = 1 wave/SIMD
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   __shared__ float s_red[32 * CT][32 * NT + 1];
@@ -123,35 +124,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 
   const float* xcol = a.x + c0 + CT * i;
   const float* gcol = a.g + n0 + NT * i;
-  // each wave walks 64-pair groups: group index = wave, wave+4, ...
-  for (int64_t g0 = pb + (int64_t)wave * 64; g0 < pe; g0 += 256) {
+  // Each wave walks 64-pair groups (group index = wave, wave+4, ...); one group is 32 MFMA contraction steps of two
+  // pairs.  The operand rows of step s+D are requested while step s multiplies (register ring of D steps, running on
+  // into the next group): written as load -> use per step, hipcc emitted global_load -> s_waitcnt vmcnt(0) -> MFMAs,
+  // the whole memory latency in front of every CT*NT MFMAs (SQ_VALU_MFMA_BUSY_CYCLES: 38 %).
+  constexpr int D = (CT * NT >= 6) ? 4 : 8;  // steps in flight: >= ~2000 cycles of matrix work (32 % D == 0)
+  float av[D][CT], bv[D][NT];
+  auto load_idx = [&](int64_t g0, int32_t& rx, int32_t& rg) {
     const int64_t p = g0 + lane;
-    int32_t rx = -1, rg = -1;
-    if (p < pe) {
-      rx = a.idx_x ? a.idx_x[p] : (int32_t)p;
-      rg = a.idx_g ? a.idx_g[p] : (int32_t)p;
+    rx = IDX ? a.idx_x[p] : (int32_t)p;  // IDX is a template flag: a run-time select put an s_waitcnt vmcnt(0) here
+    rg = IDX ? a.idx_g[p] : (int32_t)p;
+  };
+  // operands of contraction step j of a FULL group: lane (i, h) takes pair 2j+h
+#define PCMI_WGRAD_LOAD(J, RX, RG)                                                            \
+  {                                                                                           \
+    const int32_t ix0 = __builtin_amdgcn_readlane(RX, 2 * (J)), ix1 = __builtin_amdgcn_readlane(RX, 2 * (J) + 1); \
+    const int32_t ig0 = __builtin_amdgcn_readlane(RG, 2 * (J)), ig1 = __builtin_amdgcn_readlane(RG, 2 * (J) + 1); \
+    VecLoad<CT>::ld(xcol + (int64_t)(h ? ix1 : ix0) * a.x_ld, av[(J) % D]);                   \
+    VecLoad<NT>::ld(gcol + (int64_t)(h ? ig1 : ig0) * a.g_ld, bv[(J) % D]);                   \
+  }
+  int64_t g0 = pb + (int64_t)wave * 64;
+  int32_t rx = 0, rg = 0, rxn = 0, rgn = 0;
+  bool primed = false;  // ring holds steps 0..D-1 of the group at g0
+  for (; g0 + 64 <= pe; g0 += 256) {
+    const bool next_full = g0 + 256 + 64 <= pe;
+    if (!primed) {
+      load_idx(g0, rx, rg);
+#pragma unroll
+      for (int j = 0; j < D; ++j) PCMI_WGRAD_LOAD(j, rx, rg)
     }
-    const int npairs = (int)min((int64_t)64, pe - g0);
-#pragma unroll 4
+    if (next_full) load_idx(g0 + 256, rxn, rgn);
+#pragma unroll
     for (int s = 0; s < 32; ++s) {
-      if (2 * s >= npairs) break;
-      const int32_t ix = __shfl(rx, 2 * s + h, 64);
-      const int32_t ig = __shfl(rg, 2 * s + h, 64);
-      float av[CT], bv[NT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % D][ct], bv[s % D][nt], acc[ct][nt], 0, 0, 0);
+      if (s + D < 32) {
+        PCMI_WGRAD_LOAD(s + D, rx, rg)
+      } else if (next_full) {
+        PCMI_WGRAD_LOAD(s + D - 32, rxn, rgn)
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests D steps ahead of their use
+    }
+    rx = rxn;
+    rg = rgn;
+    primed = next_full;
+  }
+#undef PCMI_WGRAD_LOAD
+  // ragged last group of this wave
+  if (g0 < pe) {
+    const int64_t p = g0 + lane;
+    int32_t tx = -1, tg = -1;
+    if (p < pe) {
+      tx = IDX ? a.idx_x[p] : (int32_t)p;
+      tg = IDX ? a.idx_g[p] : (int32_t)p;
+    }
+    const int npairs = (int)(pe - g0);
+    for (int s = 0; 2 * s < npairs; ++s) {
+      const int32_t ix = __shfl(tx, 2 * s + h, 64);
+      const int32_t ig = __shfl(tg, 2 * s + h, 64);
+      float ta[CT], tb[NT];
       if (ix >= 0) {
-        VecLoad<CT>::ld(xcol + (int64_t)ix * a.x_ld, av);
-        VecLoad<NT>::ld(gcol + (int64_t)ig * a.g_ld, bv);
+        VecLoad<CT>::ld(xcol + (int64_t)ix * a.x_ld, ta);
+        VecLoad<NT>::ld(gcol + (int64_t)ig * a.g_ld, tb);
       } else {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) av[ct] = 0.f;
+        for (int ct = 0; ct < CT; ++ct) ta[ct] = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = 0.f;
+        for (int nt = 0; nt < NT; ++nt) tb[nt] = 0.f;
       }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ct], bv[nt], acc[ct][nt], 0, 0, 0);
+          acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[ct], tb[nt], acc[ct][nt], 0, 0, 0);
     }
   }
 
@@ -306,16 +354,53 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   if (lane == 0) out[col] = accumulate ? out[col] + s : s;
 }
 
+template <int CT, int NT>
+static void launch_wg(const WgradArgs& a, dim3 grid, hipStream_t st) {
+  if (a.idx_x)
+    wgrad_mfma_kernel<CT, NT, true><<<grid, 256, 0, st>>>(a);
+  else
+    wgrad_mfma_kernel<CT, NT, false><<<grid, 256, 0, st>>>(a);
+}
+
 template <int CT>
 static int launch_wg_nt(int NT, const WgradArgs& a, dim3 grid, hipStream_t st) {
   switch (NT) {
-    case 1: wgrad_mfma_kernel<CT, 1><<<grid, 256, 0, st>>>(a); break;
-    case 2: wgrad_mfma_kernel<CT, 2><<<grid, 256, 0, st>>>(a); break;
-    case 3: wgrad_mfma_kernel<CT, 3><<<grid, 256, 0, st>>>(a); break;
+    case 1: launch_wg<CT, 1>(a, grid, st); break;
+    case 2: launch_wg<CT, 2>(a, grid, st); break;
+    case 3: launch_wg<CT, 3>(a, grid, st); break;
     default: set_error("wgrad: bad NT %d", NT); return PCMI_ERR_INVALID;
   }
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
+}
+
+// resident workgroups per CU of one variant (cached; only steers the chunk size)
+template <int CT, int NT>
+static int occupancy_wg(bool idx) {
+  static int cache[2] = {0, 0};
+  int& v = cache[idx ? 1 : 0];
+  if (v == 0) {
+    int n = 0;
+    hipError_t e = idx ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_mfma_kernel<CT, NT, true>, 256, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_mfma_kernel<CT, NT, false>, 256, 0);
+    v = (e == hipSuccess && n > 0) ? std::min(n, 8) : 2;
+    (void)hipGetLastError();
+  }
+  return v;
+}
+
+static int wgrad_occupancy(int CT, int NT, bool idx) {
+  switch (CT * 4 + NT) {
+    case 1 * 4 + 1: return occupancy_wg<1, 1>(idx);
+    case 1 * 4 + 2: return occupancy_wg<1, 2>(idx);
+    case 1 * 4 + 3: return occupancy_wg<1, 3>(idx);
+    case 2 * 4 + 1: return occupancy_wg<2, 1>(idx);
+    case 2 * 4 + 2: return occupancy_wg<2, 2>(idx);
+    case 2 * 4 + 3: return occupancy_wg<2, 3>(idx);
+    case 3 * 4 + 1: return occupancy_wg<3, 1>(idx);
+    case 3 * 4 + 2: return occupancy_wg<3, 2>(idx);
+    default: return occupancy_wg<3, 3>(idx);
+  }
 }
 
 static int tiles_per_wg(int tiles32) {  // tiles (of 32 channels) a workgroup covers per axis
@@ -324,12 +409,32 @@ static int tiles_per_wg(int tiles32) {  // tiles (of 32 channels) a workgroup co
   return 1;
 }
 
-static int wgrad_chunk(int64_t M, int K) {
-  // aim at ~3 workgroups per CU worth of chunks over all offsets
-  int64_t c = ceil_div(M, 768);
-  c = std::max<int64_t>(256, std::min<int64_t>(4096, align_up((size_t)c, 256)));
-  (void)K;
-  return (int)c;
+// Pairs per workgroup.  Every chunk costs the same, so the launch runs in ceil(workgroups / resident slots)
+// rounds of equal length: 741 workgroups on 512 slots (what M/768 gave for the level-1 96->96 conv) idle half the
+// chip in the second round -- SQ_WAVE_CYCLES showed the waves alive for 47 % of the kernel.  Pick the largest
+// chunk whose workgroup count fills >= 92 % of a whole number of rounds (else the best fill).
+constexpr int kWgradMinChunk = 256, kWgradMaxChunk = 4096, kWgradMaxChunks = 1536;
+
+static int wgrad_min_chunk(int64_t M) {
+  return (int)std::max<int64_t>(kWgradMinChunk, align_up((size_t)ceil_div(M, kWgradMaxChunks), 128));
+}
+
+static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk);
+
+static int wgrad_chunk(const pcmi_kmap_t* map, int64_t M, int64_t wgs_per_chunk, int64_t slots) {
+  const int lo = wgrad_min_chunk(M);
+  int best = lo;
+  double best_fill = -1.0;
+  for (int c = std::max(lo, kWgradMaxChunk); c >= lo; c -= 128) {
+    const int64_t wgs = wgrad_num_chunks(map, M, c) * wgs_per_chunk;
+    const double fill = (double)wgs / (double)(ceil_div(wgs, slots) * slots);
+    if (fill >= 0.92) return c;
+    if (fill > best_fill) {
+      best_fill = fill;
+      best = c;
+    }
+  }
+  return best;
 }
 
 static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk) {
@@ -341,8 +446,7 @@ static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk) {
 
 size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M) {
   if (M <= 0) M = std::max(n_in, n_out);
-  const int chunk = wgrad_chunk(M, K);
-  const int64_t nchunks = ceil_div(M, chunk) + K;
+  const int64_t nchunks = ceil_div(M, wgrad_min_chunk(M)) + K;
   return (size_t)nchunks * cin * cout * sizeof(float) + (size_t)1024 * cout * sizeof(float);
 }
 
@@ -398,23 +502,32 @@ int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
   a.K = K;
   a.cin = cin;
   a.cout = cout;
-  a.chunk = wgrad_chunk(M, K);
+  const bool stem = cin < 8;
+  int CT = 1, NT = 1;
+  int64_t slots = 8 * (int64_t)num_cu(), wgs_per_chunk = 1;
+  if (stem) {
+    PCMI_REQUIRE(cin == 3 && cout % 32 == 0, PCMI_ERR_UNSUPPORTED, "spconv_bwd_weight: cin=%d only supported as the 3-channel stem", cin);
+  } else {
+    PCMI_REQUIRE(cin % 32 == 0 && cout % 32 == 0, PCMI_ERR_UNSUPPORTED,
+                 "spconv_bwd_weight: channels (%d, %d) must be multiples of 32", cin, cout);
+    PCMI_REQUIRE(in_ld % 4 == 0 && gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0,
+                 PCMI_ERR_INVALID, "spconv_bwd_weight: operands must be 16-byte aligned with ld %% 4 == 0");
+    CT = tiles_per_wg(cin / 32);
+    NT = tiles_per_wg(cout / 32);
+    wgs_per_chunk = (int64_t)(cin / (32 * CT)) * (cout / (32 * NT));
+    slots = (int64_t)wgrad_occupancy(CT, NT, a.idx_x != nullptr) * num_cu();
+  }
+  a.chunk = wgrad_chunk(map, M, wgs_per_chunk, slots);
   const int64_t nchunks = wgrad_num_chunks(map, M, a.chunk);
   const size_t slab_bytes = (size_t)nchunks * per_k * sizeof(float);
   const size_t bias_bytes = gbias ? (size_t)1024 * cout * sizeof(float) : 0;
   PCMI_REQUIRE(ws && ws_bytes >= slab_bytes + bias_bytes, PCMI_ERR_WORKSPACE,
                "spconv_bwd_weight: workspace %zu < %zu bytes", ws_bytes, slab_bytes + bias_bytes);
   a.slabs = (float*)ws;
-  if (cin < 8) {
-    PCMI_REQUIRE(cin == 3 && cout % 32 == 0, PCMI_ERR_UNSUPPORTED, "spconv_bwd_weight: cin=%d only supported as the 3-channel stem", cin);
+  if (stem) {
     stem_wgrad_kernel<3><<<dim3((unsigned)nchunks), 256, 0, st>>>(a);
     PCMI_LAUNCH_CHECK();
   } else {
-    PCMI_REQUIRE(cin % 32 == 0 && cout % 32 == 0, PCMI_ERR_UNSUPPORTED,
-                 "spconv_bwd_weight: channels (%d, %d) must be multiples of 32", cin, cout);
-    PCMI_REQUIRE(in_ld % 4 == 0 && gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0,
-                 PCMI_ERR_INVALID, "spconv_bwd_weight: operands must be 16-byte aligned with ld %% 4 == 0");
-    const int CT = tiles_per_wg(cin / 32), NT = tiles_per_wg(cout / 32);
     dim3 grid((unsigned)nchunks, (unsigned)(cin / (32 * CT)), (unsigned)(cout / (32 * NT)));
     int rc;
     switch (CT) {

@@ -55,3 +55,15 @@ n0 = cm.size(keys[0])
 run("L0 1x1 128->96", None, 1, 128, 96, n0, n0)
 run("L0 1x1 96->32", None, 1, 96, 32, n0, n0)
 print("sum of the listed shapes: fwd %.2f ms, bwd %.2f ms, wgrad %.2f ms" % (tot["fwd"], tot["bwd"], tot["wgrad"]))
+
+# sustained clocks: the same level-1 96->96 forward in consecutive blocks of 100 launches (a drop from the first
+# block to the later ones is the power/thermal governor, not the kernel)
+if os.environ.get("KBENCH_SUSTAINED", "1") == "1":
+  m = cm.kernel_map(keys[0], keys[0], 3, 1, 3)
+  W = torch.randn(27, 96, 96, device=dev) * 0.05
+  x, y = torch.randn(n0, 96, device=dev), torch.empty(n0, 96, device=dev)
+  ws, wsb = ws_args(lib.pcmi_spconv_workspace_bytes(n0, n0, 96, 96, 27, m.M), dev)
+  s = cur_stream(dev)
+  f = lambda: check(lib.pcmi_spconv_fwd(ptr(x), 96, n0, 96, ptr(W), 96, C.byref(m), 0, None, ptr(y), 96, n0, ws, wsb, s))
+  print("sustained 96->96 fwd, ms per launch in blocks of 100:",
+        " ".join("%.3f" % (bench.time_kernel(f, iters=100, warm=0) * 1e3) for _ in range(10)), flush=True)
