@@ -11,6 +11,7 @@
 // range) overwrites, later ones accumulate inside the producing kernel's epilogue (no separate add
 // kernels, no zero-fill of activation gradients).  Which is which is decided once, at creation.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -72,6 +73,19 @@ struct pcmi_net {
   std::vector<size_t> grad_off;
   pcmi::DevBuf ws;
   pcmi::DevBuf small;  // dgamma/dbeta scratch
+  // backward: the weight gradients (off the critical path: nothing downstream reads them) run on a side stream
+  // next to the bwd-data -> BN-bwd chain; their slabs need a workspace of their own
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  pcmi::DevBuf ws_side;
+  ~pcmi_net() {
+    if (side) {
+      (void)hipStreamSynchronize(side);
+      (void)hipStreamDestroy(side);
+    }
+    if (ev_main) (void)hipEventDestroy(ev_main);
+    if (ev_side) (void)hipEventDestroy(ev_side);
+  }
 };
 
 namespace pcmi {
@@ -196,7 +210,7 @@ int pcmi_net_destroy(pcmi_net_t* net) {
 
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
-  size_t b = net->grad.cap + net->ws.cap + net->small.cap;
+  size_t b = net->grad.cap + net->ws.cap + net->ws_side.cap + net->small.cap;
   for (auto& p : net->passes) b += p.act.cap;
   *bytes = b;
   return PCMI_OK;
@@ -327,6 +341,31 @@ int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_l
   rc = n.small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
   if (rc) return rc;
   float* scratch_g = (float*)n.small.p;
+  static const bool side_enabled = [] {
+    const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
+    return !(e && e[0] == '0');
+  }();
+  hipStream_t wst = st;  // stream of the weight-gradient kernels
+  pcmi::DevBuf* wws = &n.ws;
+  if (side_enabled) {
+    if (!n.side) {
+      PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking));
+      PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main, hipEventDisableTiming));
+      PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side, hipEventDisableTiming));
+    }
+    rc = n.ws_side.reserve(n.ws.cap, n.side);
+    if (rc) return rc;
+    wst = n.side;
+    wws = &n.ws_side;
+  }
+  bool side_pending = false;
+  auto join_side = [&]() -> int {  // `st` continues only after the weight gradients enqueued so far
+    if (!side_pending) return PCMI_OK;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_side, n.side));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side, 0));
+    side_pending = false;
+    return PCMI_OK;
+  };
   // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
   std::vector<int> bucket_last(std::max(n_buckets, 0), -1);
   auto bucket_of = [&](int64_t offp) {
@@ -351,14 +390,19 @@ int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_l
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
     if (op.type == PCMI_OP_CONV) {
       const pcmi_kmap_t* map = ps.has_map[i] ? &ps.maps[i] : nullptr;
+      if (wst != st) {  // dy is complete at this point of `st` (all its consumers were differentiated before)
+        PCMI_HIP_CHECK(hipEventRecord(n.ev_main, st));
+        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main, 0));
+        side_pending = true;
+      }
+      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
+                                  grads + op.w_off, op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
+      if (rc) return rc;
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, op.in, d_out, d_ld);
         rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
                                   n_in, pl.acc_in, n.ws.p, n.ws.cap, st);
-        if (rc) return rc;
       }
-      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
-                                  grads + op.w_off, op.has_bias ? grads + op.b_off : nullptr, 1, n.ws.p, n.ws.cap, st);
     } else if (op.type == PCMI_OP_BN) {
       const View dx = grad_view(n, op.in, d_out, d_ld);
       View dr = {nullptr, 0};
@@ -375,8 +419,14 @@ int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_l
     if (rc) return rc;
     if (ready)
       for (int b = 0; b < n_buckets; ++b)
-        if (bucket_last[b] == i) ready(ready_ctx, b);
+        if (bucket_last[b] == i) {
+          rc = join_side();
+          if (rc) return rc;
+          ready(ready_ctx, b);
+        }
   }
+  rc = join_side();  // the gradient arena / grads are reused by whatever `st` runs next
+  if (rc) return rc;
   ps.valid = false;
   return PCMI_OK;
 }
