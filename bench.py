@@ -224,6 +224,7 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
   ap.add_argument("--layer-table", default=None, help="write the per-layer work table to this path")
+  ap.add_argument("--set", action="append", default=[], metavar="a.b=c", help="extra config override (A/B experiments)")
   args = ap.parse_args()
 
   import torch
@@ -247,7 +248,7 @@ def main():
   from pointcontrast_amd.lib.timer import AverageMeter, Timer
   cfg = get_config(["net.model=%s" % args.model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1",
                     "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world),
-                    "misc.engine=%s" % args.engine])
+                    "misc.engine=%s" % args.engine] + list(args.set))
   batch = get_batch(seed=rank, batch_size=args.batch, voxel_size=args.voxel)
   loader = FixedBatchLoader([batch], batch_size=args.batch)
   torch.manual_seed(0)

@@ -296,7 +296,13 @@ int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_
                     int n_ops, int input_tensor, int output_tensor, int n_passes, pcmi_net_t** out);
 int pcmi_net_destroy(pcmi_net_t* net);
 /* in_feats [n_rows, in_ld] and out_feats [n_rows, out_ld] are caller memory; coords must hold
- * key 0 with n_rows rows.  May sync the first times (arena growth, coordinate planning). */
+ * key 0 with n_rows rows.  May sync the first times (arena growth, coordinate planning).
+ * training: 0 = eval (running BN estimates), 1 = train (batch statistics, running estimates
+ * updated in place as torch's BatchNorm1d), 1 | PCMI_NET_DEFER_RUNNING_STATS = train, but the
+ * running-estimate updates of this pass are only applied by pcmi_net_apply_running_stats: two
+ * passes (the two clouds of a pair, ddp_trainer.py:404-407) can then be forwarded concurrently
+ * on two streams and still update the estimates in the reference's order (pass 0, then 1). */
+#define PCMI_NET_DEFER_RUNNING_STATS 2
 int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const float* in_feats,
                      int64_t in_ld, int64_t n_rows, const float* params, int training,
                      float* out_feats, int64_t out_ld, pcmi_stream_t stream);
@@ -306,6 +312,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
 int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_ld,
                       const float* params, float* grads, const int64_t* bucket_lo_host,
                       int n_buckets, pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream);
+int pcmi_net_apply_running_stats(pcmi_net_t* net, int pass, pcmi_stream_t stream);
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes);
 
 #ifdef __cplusplus

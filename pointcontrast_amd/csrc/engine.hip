@@ -22,11 +22,13 @@ namespace pcmi {
 struct DevBuf {
   char* p = nullptr;
   size_t cap = 0;
-  // grows with 25 % head-room; the old block may still be in flight -> sync before freeing it
+  // grows with 25 % head-room; the old block may still be in flight (on any of the executor's streams) -> sync
+  // the device before freeing it (growth happens in the first iterations only)
   int reserve(size_t bytes, hipStream_t st) {
     if (bytes <= cap) return PCMI_OK;
+    (void)st;
     if (p) {
-      PCMI_HIP_CHECK(hipStreamSynchronize(st));
+      PCMI_HIP_CHECK(hipDeviceSynchronize());
       PCMI_HIP_CHECK(hipFree(p));
       p = nullptr;
       cap = 0;
@@ -48,6 +50,17 @@ struct OpPlan {
 
 struct PassState {
   DevBuf act;
+  DevBuf ws;  // forward workspace of this pass (passes may be forwarded concurrently on different streams)
+  // deferred BatchNorm running-estimate updates of this pass (training & PCMI_NET_DEFER_RUNNING_STATS)
+  BnRunningUpdate* upd_host = nullptr;  // pinned
+  BnRunningUpdate* upd_dev = nullptr;
+  int upd_cap = 0, upd_n = 0;
+  hipEvent_t upd_copied = nullptr;
+  ~PassState() {
+    if (upd_host) (void)hipHostFree(upd_host);
+    if (upd_dev) (void)hipFree(upd_dev);
+    if (upd_copied) (void)hipEventDestroy(upd_copied);
+  }
   std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
   std::vector<size_t> stat_off;    // per op: BN save_mean/save_invstd (2*C floats) or L2 norms
   std::vector<pcmi_kmap_t> maps;   // per op
@@ -211,7 +224,7 @@ int pcmi_net_destroy(pcmi_net_t* net) {
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
   size_t b = net->grad.cap + net->ws.cap + net->ws_side.cap + net->small.cap;
-  for (auto& p : net->passes) b += p.act.cap;
+  for (auto& p : net->passes) b += p.act.cap + p.ws.cap;
   *bytes = b;
   return PCMI_OK;
 }
@@ -275,13 +288,32 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
     ps.stat_off[i] = off;
-    if (op.type == PCMI_OP_BN) off += align_up((size_t)2 * op.cout * sizeof(float), 256);
+    if (op.type == PCMI_OP_BN) off += align_up((size_t)3 * op.cout * sizeof(float), 256);  // mean, invstd, unbiased var
     if (op.type == PCMI_OP_L2NORM) off += align_up((size_t)ps.rows[n.tensors[op.in].level] * sizeof(float), 256);
   }
   rc = ps.act.reserve(off, st);
   if (rc) return rc;
-  rc = n.ws.reserve(ws_need + 256, st);
+  rc = ps.ws.reserve(ws_need + 256, st);
   if (rc) return rc;
+  rc = n.ws.reserve(ws_need + 256, st);  // backward (main chain); the side stream sizes its own from this one
+  if (rc) return rc;
+  const bool train = (training & 1) != 0, defer = train && (training & PCMI_NET_DEFER_RUNNING_STATS) != 0;
+  ps.upd_n = 0;
+  if (defer) {
+    int n_bn = 0;
+    for (int i = 0; i < n_ops; ++i) n_bn += n.ops[i].type == PCMI_OP_BN;
+    if (n_bn > ps.upd_cap) {
+      PCMI_HIP_CHECK(hipDeviceSynchronize());
+      if (ps.upd_host) PCMI_HIP_CHECK(hipHostFree(ps.upd_host));
+      if (ps.upd_dev) PCMI_HIP_CHECK(hipFree(ps.upd_dev));
+      ps.upd_host = ps.upd_dev = nullptr;
+      PCMI_HIP_CHECK(hipHostMalloc((void**)&ps.upd_host, sizeof(BnRunningUpdate) * n_bn, hipHostMallocDefault));
+      PCMI_HIP_CHECK(hipMalloc((void**)&ps.upd_dev, sizeof(BnRunningUpdate) * n_bn));
+      ps.upd_cap = n_bn;
+    }
+    if (!ps.upd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.upd_copied, hipEventDisableTiming));
+    PCMI_HIP_CHECK(hipEventSynchronize(ps.upd_copied));  // the previous table has left the pinned buffer
+  }
   ps.in_feats = in_feats;
   ps.in_ld = in_ld;
   ps.out_feats = out_feats;
@@ -294,26 +326,41 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
     if (op.type == PCMI_OP_CONV) {
       rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
-                          op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, n.ws.p, n.ws.cap,
+                          op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, ps.ws.p, ps.ws.cap,
                           st);
     } else if (op.type == PCMI_OP_BN) {
       View r = {nullptr, 0};
       if (op.in2 >= 0) r = act_view(n, ps, op.in2);
       float* stats = (float*)(ps.act.p + ps.stat_off[i]);
-      if (training)
-        rc = pcmi_bn_fwd_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
-                               op.running_var, op.momentum, op.eps, r.p, r.ld, op.relu, y.p, y.ld, stats,
-                               stats + op.cout, n.ws.p, n.ws.cap, stream);
-      else
+      if (train) {
+        rc = bn_forward_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off,
+                              defer ? nullptr : op.running_mean, defer ? nullptr : op.running_var, op.momentum, op.eps, r.p,
+                              r.ld, op.relu, y.p, y.ld, stats, stats + op.cout, stats + 2 * op.cout, ps.ws.p, ps.ws.cap, st);
+        if (defer && op.running_mean)
+          ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats, stats + 2 * op.cout, op.cout, op.momentum};
+      } else {
         rc = pcmi_bn_fwd_eval(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
                               op.running_var, op.eps, r.p, r.ld, op.relu, y.p, y.ld, stream);
+      }
     } else {
       rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), stream);
     }
     if (rc) return rc;
   }
-  ps.valid = training != 0;
+  if (defer && ps.upd_n > 0) {
+    PCMI_HIP_CHECK(hipMemcpyAsync(ps.upd_dev, ps.upd_host, sizeof(BnRunningUpdate) * ps.upd_n, hipMemcpyHostToDevice, st));
+    PCMI_HIP_CHECK(hipEventRecord(ps.upd_copied, st));
+  }
+  ps.valid = train;
   return PCMI_OK;
+}
+
+int pcmi_net_apply_running_stats(pcmi_net_t* net, int pass, pcmi_stream_t stream) {
+  PCMI_REQUIRE(net && pass >= 0 && pass < (int)net->passes.size(), PCMI_ERR_INVALID, "net_apply_running_stats: bad argument");
+  PassState& ps = net->passes[pass];
+  const int n_upd = ps.upd_n;
+  ps.upd_n = 0;  // applied once
+  return bn_running_update(ps.upd_dev, n_upd, as_stream(stream));
 }
 
 int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_ld, const float* params, float* grads,

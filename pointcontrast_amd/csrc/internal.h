@@ -18,6 +18,21 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
                 int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,
                 float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
 
+int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                     int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean, float* save_invstd,
+                     float* save_unbiased, void* ws, size_t ws_bytes, hipStream_t st);
+// deferred running-estimate update of one BatchNorm layer: running = (1 - momentum) * running + momentum * batch
+struct BnRunningUpdate {
+  float* running_mean;
+  float* running_var;
+  const float* mean;
+  const float* unbiased;
+  int c;
+  float momentum;
+};
+int bn_running_update(const BnRunningUpdate* table_dev, int n_entries, hipStream_t st);
+
 size_t sort_rows_temp_bytes(int64_t n);
 int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, uint32_t* mask_in, uint32_t* mask_out,
                       int32_t* iota, void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st);

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "internal.h"
 
 namespace pcmi {
 
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var,
                                                              float* __restrict__ save_mean,
-                                                             float* __restrict__ save_invstd) {
+                                                             float* __restrict__ save_invstd,
+                                                             float* __restrict__ save_unbiased) {
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ch >= c) return;
@@ -136,8 +138,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
   const float var = m2 / cnt;
   save_mean[ch] = mean;
   save_invstd[ch] = 1.0f / sqrtf(var + eps);
+  const float unbiased = cnt > 1.f ? m2 / (cnt - 1.f) : var;
+  if (save_unbiased) save_unbiased[ch] = unbiased;
   if (running_mean) {
-    const float unbiased = cnt > 1.f ? m2 / (cnt - 1.f) : var;
     running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * mean;
     running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
   }
@@ -328,7 +331,8 @@ __global__ __launch_bounds__(kSmallThreads) void bn_small_fwd_kernel(const float
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            float momentum, float eps, const float* __restrict__ res,
                                                            int64_t res_ld, int relu, float* __restrict__ y, int64_t y_ld,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                           float* __restrict__ save_unbiased) {
   __shared__ float s_n[kSmallThreads];
   __shared__ float4 s_mean[kSmallThreads];
   __shared__ float4 s_m2[kSmallThreads];
@@ -363,8 +367,10 @@ __global__ __launch_bounds__(kSmallThreads) void bn_small_fwd_kernel(const float
   if (t == 0) {
     reinterpret_cast<float4*>(save_mean)[col] = mean;
     reinterpret_cast<float4*>(save_invstd)[col] = is;
+    const float ub = cnt > 1.f ? cnt / (cnt - 1.f) : 1.f;
+    if (save_unbiased)
+      reinterpret_cast<float4*>(save_unbiased)[col] = make_float4(var.x * ub, var.y * ub, var.z * ub, var.w * ub);
     if (running_mean) {
-      const float ub = cnt > 1.f ? cnt / (cnt - 1.f) : 1.f;
       float4 rm = reinterpret_cast<float4*>(running_mean)[col], rv = reinterpret_cast<float4*>(running_var)[col];
       const float om = 1.f - momentum;
       rm = make_float4(om * rm.x + momentum * mean.x, om * rm.y + momentum * mean.y, om * rm.z + momentum * mean.z,
@@ -483,6 +489,20 @@ int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const floa
                       float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                       int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean, float* save_invstd,
                       void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  return pcmi::bn_forward_train(x, x_ld, n, c, gamma, beta, running_mean, running_var, momentum, eps, residual, res_ld, relu, y,
+                                y_ld, save_mean, save_invstd, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+}  // extern "C"
+
+namespace pcmi {
+
+// running_mean / running_var may be null (no update) and save_unbiased non-null: the executor then applies the
+// running-estimate update later, in program order, with bn_running_update (two passes forwarded concurrently).
+int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                     int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean, float* save_invstd,
+                     float* save_unbiased, void* ws, size_t ws_bytes, hipStream_t st) {
   int rc = check_rows("bn_fwd_train(x)", x, x_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_fwd_train(y)", y, y_ld, c);
@@ -490,10 +510,9 @@ int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const floa
   if (residual && (rc = check_rows("bn_fwd_train(residual)", residual, res_ld, c))) return rc;
   PCMI_REQUIRE(gamma && beta && save_mean && save_invstd && n > 0 && c <= 1024, PCMI_ERR_INVALID, "bn_fwd_train: bad argument");
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_fwd_train: workspace too small");
-  hipStream_t st = as_stream(stream);
   if (n <= kSmallRows) {
     bn_small_fwd_kernel<<<c / 4, kSmallThreads, 0, st>>>(x, x_ld, n, gamma, beta, running_mean, running_var, momentum, eps, residual, res_ld,
-                                               relu, y, y_ld, save_mean, save_invstd);
+                                               relu, y, y_ld, save_mean, save_invstd, save_unbiased);
     PCMI_LAUNCH_CHECK();
     return PCMI_OK;
   }
@@ -503,13 +522,34 @@ int pcmi_bn_fwd_train(const float* x, int64_t x_ld, int64_t n, int c, const floa
                                                         g.rows_per_block, part);
   PCMI_LAUNCH_CHECK();
   bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
-                                                                       running_mean, running_var, save_mean, save_invstd);
+                                                                       running_mean, running_var, save_mean, save_invstd,
+                                                                       save_unbiased);
   PCMI_LAUNCH_CHECK();
   bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
                                                         res_ld, relu, y, y_ld);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
+
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const BnRunningUpdate* __restrict__ tab) {
+  const BnRunningUpdate u = tab[blockIdx.x];
+  for (int ch = threadIdx.x; ch < u.c; ch += 256) {
+    u.running_mean[ch] = (1.f - u.momentum) * u.running_mean[ch] + u.momentum * u.mean[ch];
+    u.running_var[ch] = (1.f - u.momentum) * u.running_var[ch] + u.momentum * u.unbiased[ch];
+  }
+}
+
+int bn_running_update(const BnRunningUpdate* table_dev, int n_entries, hipStream_t st) {
+  if (n_entries <= 0) return PCMI_OK;
+  bn_running_update_kernel<<<n_entries, 256, 0, st>>>(table_dev);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+}  // namespace pcmi
+
+extern "C" {
+
 
 int pcmi_bn_fwd_eval(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
                      const float* running_mean, const float* running_var, float eps, const float* residual,

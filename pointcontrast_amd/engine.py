@@ -112,6 +112,7 @@ class NativeEngine:
     self.n_ops, self.n_tensors = len(prog["ops"]), len(prog["tensors"])
     self._h = create_net(prog, n_passes)
     self._held = [None] * n_passes
+    self._pair_stream = None
 
   def __del__(self):
     try:
@@ -122,8 +123,9 @@ class NativeEngine:
     except Exception:
       pass
 
-  def forward(self, pass_id, st, training=True):
-    """st: ME.SparseTensor on the device.  Returns the output features [N, out_channels]."""
+  def forward(self, pass_id, st, training=True, defer_running_stats=False):
+    """st: ME.SparseTensor on the device.  Returns the output features [N, out_channels].
+    Enqueued on torch's current stream.  defer_running_stats: see apply_running_stats."""
     x = st.F
     require_cuda(x, "NativeEngine.forward")
     x = x if (x.stride(1) == 1 and x.dtype == torch.float32) else x.float().contiguous()
@@ -132,13 +134,38 @@ class NativeEngine:
     n = x.shape[0]
     out = torch.empty((n, self.out_channels), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-      check(lib.pcmi_net_forward(self._h, pass_id, cm._h, ptr(x), x.stride(0), n, ptr(self.flat.w), int(training), ptr(out),
+      mode = (1 if training else 0) | (2 if (training and defer_running_stats) else 0)  # PCMI_NET_DEFER_RUNNING_STATS
+      check(lib.pcmi_net_forward(self._h, pass_id, cm._h, ptr(x), x.stride(0), n, ptr(self.flat.w), mode, ptr(out),
                                  self.out_channels, cur_stream(x.device)))
     if training:
       for m in self._bn_modules:
         m._untracked += 1
       self._held[pass_id] = (st, x, out)  # coordinates / input / output stay alive until backward
     return out
+
+  def apply_running_stats(self, pass_id):
+    """Applies the BatchNorm running-estimate updates a forward(..., defer_running_stats=True) of this pass left
+    pending (on the current stream, which must be ordered after that forward)."""
+    with torch.cuda.device(self.flat.w.device):
+      check(lib.pcmi_net_apply_running_stats(self._h, pass_id, cur_stream(self.flat.w.device)))
+
+  def forward_pair(self, st0, st1):
+    """The two forwards of a training iteration (ddp_trainer.py:404-407 of the reference runs them back to back):
+    pass 1 is enqueued on a side stream, pass 0 on the current one, so that the small levels of one pass fill the
+    CUs the other leaves idle.  BatchNorm running estimates are still updated in the order pass 0, pass 1."""
+    dev = self.flat.w.device
+    cur = torch.cuda.current_stream(dev)
+    if self._pair_stream is None:
+      self._pair_stream = torch.cuda.Stream(device=dev)
+    side = self._pair_stream
+    side.wait_stream(cur)  # inputs / parameters were produced on the current stream
+    with torch.cuda.stream(side):
+      f1 = self.forward(1, st1, defer_running_stats=True)
+    f0 = self.forward(0, st0)
+    cur.wait_stream(side)
+    f1.record_stream(cur)
+    self.apply_running_stats(1)
+    return f0, f1
 
   def backward(self, pass_id, d_out, reducer=None):
     """Accumulates parameter gradients of pass `pass_id` into flat.g.  With a GradReducer the

@@ -175,8 +175,12 @@ class ContrastiveLossTrainer:
     s0, s1 = prep["s0"], prep["s1"]
     if self.engine is None:
       return self.model(s0).F, self.model(s1).F
-    F0 = self.engine.forward(0, s0, self.model.training).requires_grad_(True)
-    F1 = self.engine.forward(1, s1, self.model.training).requires_grad_(True)
+    if self.model.training and self.config.misc.get("concurrent_forward", True):
+      F0, F1 = self.engine.forward_pair(s0, s1)  # two streams, same results
+      F0, F1 = F0.requires_grad_(True), F1.requires_grad_(True)
+    else:
+      F0 = self.engine.forward(0, s0, self.model.training).requires_grad_(True)
+      F1 = self.engine.forward(1, s1, self.model.training).requires_grad_(True)
     self._feats = (F0, F1)
     return F0, F1
 

@@ -539,6 +539,20 @@ def test_engine_matches_autograd_path(ME, name, crop, batch):
     if "running" in k:
       assert_close(v, rs_after[k], 1e-5, "engine " + k)
   assert eng.memory_bytes() > 0
+  # the two passes forwarded concurrently (pass 1 on a side stream, running estimates deferred): same kernels on
+  # the same data -> bit-identical features; the running estimates are updated in the same order (pass 0, pass 1)
+  dev.load_state_dict({**dev.state_dict(), **rs})
+  torch.cuda.synchronize()
+  f0, f1 = eng.forward_pair(sts[0], sts[1])
+  torch.cuda.synchronize()
+  assert torch.equal(f0, fe[0]) and torch.equal(f1, fe[1]), "forward_pair differs from two sequential forwards"
+  for k, v in dev.state_dict().items():
+    if "running" in k:
+      assert_close(v, rs_after[k], 1e-5, "forward_pair " + k)
+  flat.zero_grad()
+  eng.backward(1, g[1])
+  eng.backward(0, g[0])
+  torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("which", ["nce", "hardest"])
