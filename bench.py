@@ -268,6 +268,7 @@ def main():
   t0 = time.perf_counter()
   for _ in range(args.steps):
     res = trainer._train_iter(it, timers)
+  host_enqueue = time.perf_counter() - t0  # host side of the K steps (nothing inside them synchronises)
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
@@ -298,6 +299,9 @@ def main():
                                "forward pair on rank 0, npos 4096, T 0.4, SGD(lr 0.1, mom 0.8, wd 1e-4)"
                                % (1 if args.loss == "nce" else 2, args.model, args.loss, args.voxel, args.batch, n0, n1),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine, "final_loss": round(loss_val, 5),
+                   "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+                   **({"host_phase_ms_per_step": {k: round(v / (args.steps + args.warmup), 3) for k, v in trainer.host_ms.items()}}
+                      if trainer.host_ms else {}),
                    "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3)},
     }
     if args.layer_table:

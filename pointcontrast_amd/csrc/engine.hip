@@ -11,6 +11,8 @@
 // range) overwrites, later ones accumulate inside the producing kernel's epilogue (no separate add
 // kernels, no zero-fill of activation gradients).  Which is which is decided once, at creation.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -18,6 +20,34 @@
 #include "internal.h"
 
 namespace pcmi {
+
+// PCMI_HOST_PROFILE=1: host-clock time per section of the executor calls, printed every 64 forwards (stderr)
+struct HostProfile {
+  bool on;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long calls = 0;
+  std::chrono::steady_clock::time_point t;
+  HostProfile() {
+    const char* e = getenv("PCMI_HOST_PROFILE");
+    on = e && e[0] == '1';
+  }
+  void start() {
+    if (on) t = std::chrono::steady_clock::now();
+  }
+  void lap(int slot) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    acc[slot] += std::chrono::duration<double, std::milli>(now - t).count();
+    t = now;
+  }
+  void report(const char* what, const char* const* names, int n) {
+    if (!on || (++calls % 64) != 0) return;
+    fprintf(stderr, "[pcmi host profile] %s, ms per call:", what);
+    for (int i = 0; i < n; ++i) fprintf(stderr, " %s %.3f", names[i], acc[i] / (double)calls);
+    fprintf(stderr, "\n");
+  }
+};
+static HostProfile g_prof_fwd, g_prof_bwd;
 
 struct DevBuf {
   char* p = nullptr;
@@ -48,6 +78,8 @@ struct OpPlan {
   int acc_res = 0;  // gradient w.r.t. `in2` (BN residual) accumulates
 };
 
+struct BnGradAdd;
+
 struct PassState {
   DevBuf act;
   DevBuf ws;  // forward workspace of this pass (passes may be forwarded concurrently on different streams)
@@ -56,10 +88,27 @@ struct PassState {
   BnRunningUpdate* upd_dev = nullptr;
   int upd_cap = 0, upd_n = 0;
   hipEvent_t upd_copied = nullptr;
+  // backward: gradient arena (activation gradients) and scratch of this pass
+  DevBuf grad;
+  std::vector<size_t> grad_off;
+  DevBuf small;  // dgamma / dbeta scratch
+  // pass run as the DEFERRED half of pcmi_net_backward_pair: BN parameter-gradient slots, the table that adds
+  // them to the flat gradients, and how far the pass got at every bucket boundary (event + table size)
+  DevBuf bn_slots;
+  BnGradAdd* gadd_host = nullptr;  // pinned
+  BnGradAdd* gadd_dev = nullptr;
+  int gadd_cap = 0, gadd_n = 0;
+  hipEvent_t gadd_copied = nullptr;
+  std::vector<int> gadd_mark;
+  std::vector<hipEvent_t> bucket_ev;
   ~PassState() {
     if (upd_host) (void)hipHostFree(upd_host);
     if (upd_dev) (void)hipFree(upd_dev);
     if (upd_copied) (void)hipEventDestroy(upd_copied);
+    if (gadd_host) (void)hipHostFree(gadd_host);
+    if (gadd_dev) (void)hipFree(gadd_dev);
+    if (gadd_copied) (void)hipEventDestroy(gadd_copied);
+    for (hipEvent_t e : bucket_ev) (void)hipEventDestroy(e);
   }
   std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
   std::vector<size_t> stat_off;    // per op: BN save_mean/save_invstd (2*C floats) or L2 norms
@@ -82,22 +131,19 @@ struct pcmi_net {
   std::vector<pcmi::OpPlan> plan;
   int input_tensor = -1, output_tensor = -1, n_levels = 0;
   std::vector<pcmi::PassState> passes;
-  pcmi::DevBuf grad;
-  std::vector<size_t> grad_off;
-  pcmi::DevBuf ws;
-  pcmi::DevBuf small;  // dgamma/dbeta scratch
   // backward: the weight gradients (off the critical path: nothing downstream reads them) run on a side stream
   // next to the bwd-data -> BN-bwd chain; their slabs need a workspace of their own
   hipStream_t side = nullptr;
-  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  hipStream_t chain1 = nullptr;  // chain stream of pass 1 in pcmi_net_backward_pair
+  hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_fork = nullptr;
   pcmi::DevBuf ws_side;
   ~pcmi_net() {
-    if (side) {
-      (void)hipStreamSynchronize(side);
-      (void)hipStreamDestroy(side);
-    }
+    (void)hipDeviceSynchronize();
+    if (side) (void)hipStreamDestroy(side);
+    if (chain1) (void)hipStreamDestroy(chain1);
     if (ev_main) (void)hipEventDestroy(ev_main);
     if (ev_side) (void)hipEventDestroy(ev_side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
   }
 };
 
@@ -129,10 +175,10 @@ static View act_view(const pcmi_net& n, const PassState& ps, int t) {
   return {base + col_of(n, t), (int64_t)n.tensors[r].channels};
 }
 
-static View grad_view(const pcmi_net& n, int t, const float* d_out, int64_t d_ld) {
+static View grad_view(const pcmi_net& n, const PassState& ps, int t, const float* d_out, int64_t d_ld) {
   if (t == n.output_tensor) return {const_cast<float*>(d_out), d_ld};
   const int r = root_of(n, t);
-  float* base = (float*)(n.grad.p + n.grad_off[r]);
+  float* base = (float*)(ps.grad.p + ps.grad_off[r]);
   return {base + col_of(n, t), (int64_t)n.tensors[r].channels};
 }
 
@@ -143,6 +189,237 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
   }
   if (op.type == PCMI_OP_BN) return pcmi_bn_workspace_bytes(n_in, op.cout);
   return 0;
+}
+
+// ---- backward -----------------------------------------------------------------------------------------
+// One pass's backward is a chain (bwd-data -> BN-bwd -> ...) on a "chain" stream plus the weight gradients,
+// which nothing downstream reads, on the shared side stream.  pcmi_net_backward_pair runs the two passes of an
+// iteration next to each other: pass 1 (DEFERRED) on the executor's second chain stream, pass 0 (PRIMARY) on
+// the caller's; both enqueue their weight gradients on the ONE side stream (pass 1 first, so the accumulation
+// order into `grads` is that of two sequential backwards).  The BN parameter gradients of the DEFERRED pass go
+// to per-op slots and are added to `grads` by the PRIMARY pass before a bucket is declared final.
+struct BackwardJob {
+  enum Role { SOLO, DEFERRED, PRIMARY };
+  int pass = 0;
+  const float* d_out = nullptr;
+  int64_t d_ld = 0;
+  hipStream_t st = nullptr;
+  Role role = SOLO;
+};
+
+struct BnGradAdd {  // grads[dst_gamma + ch] += src[ch]; grads[dst_beta + ch] += src[c + ch]
+  float* dst_gamma;
+  float* dst_beta;
+  const float* src;
+  int c;
+};
+
+__global__ __launch_bounds__(256) void bn_grad_add_kernel(const BnGradAdd* __restrict__ tab) {
+  const BnGradAdd e = tab[blockIdx.x];
+  for (int ch = threadIdx.x; ch < e.c; ch += 256) {
+    e.dst_gamma[ch] += e.src[ch];
+    e.dst_beta[ch] += e.src[e.c + ch];
+  }
+}
+
+static int ensure_streams(pcmi_net& n) {
+  if (n.side) return PCMI_OK;
+  // the weight gradients are off the critical path: lowest priority, so that the chain's kernels are dispatched
+  // first and the weight-gradient workgroups fill what they leave idle (PCMI_WGRAD_PRIORITY=0: same priority)
+  int least = 0, greatest = 0;
+  PCMI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const char* pe = getenv("PCMI_WGRAD_PRIORITY");
+  const int prio = (pe && pe[0] == '0') ? 0 : least;
+  PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio));
+  PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.chain1, hipStreamNonBlocking));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main, hipEventDisableTiming));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side, hipEventDisableTiming));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
+  return PCMI_OK;
+}
+
+static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params, float* grads,
+                        const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready, void* ready_ctx) {
+  hipStream_t st = job.st;
+  PassState& ps = n.passes[job.pass];
+  const float* d_out = job.d_out;
+  const int64_t d_ld = job.d_ld;
+  const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
+  if (n_buckets < 0 || !bucket_lo_host) n_buckets = 0;
+  // gradient arena of this pass (its own: the two passes of a pair run concurrently)
+  ps.grad_off.assign(n_t, 0);
+  size_t off = 0;
+  int max_c = 4;
+  for (int t = 0; t < n_t; ++t) {
+    max_c = std::max(max_c, n.tensors[t].channels);
+    if (n.tensors[t].parent >= 0 || t == n.input_tensor || t == n.output_tensor) continue;
+    ps.grad_off[t] = off;
+    off += align_up((size_t)ps.rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
+  }
+  int rc = ps.grad.reserve(off, st);
+  if (rc) return rc;
+  rc = ps.small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
+  if (rc) return rc;
+  float* scratch_g = (float*)ps.small.p;
+  const bool deferred = job.role == BackwardJob::DEFERRED, primary = job.role == BackwardJob::PRIMARY;
+  PassState* peer = primary ? &n.passes[1] : nullptr;
+  // ---- deferred BN parameter gradients: slots + table ------------------------------------------------
+  int n_bn = 0;
+  size_t slot_bytes = 0;
+  if (deferred) {
+    for (int i = 0; i < n_ops; ++i)
+      if (n.ops[i].type == PCMI_OP_BN) {
+        ++n_bn;
+        slot_bytes += align_up((size_t)2 * n.ops[i].cout * sizeof(float), 256);
+      }
+    rc = ps.bn_slots.reserve(slot_bytes, st);
+    if (rc) return rc;
+    if (n_bn > ps.gadd_cap) {
+      PCMI_HIP_CHECK(hipDeviceSynchronize());
+      if (ps.gadd_host) PCMI_HIP_CHECK(hipHostFree(ps.gadd_host));
+      if (ps.gadd_dev) PCMI_HIP_CHECK(hipFree(ps.gadd_dev));
+      ps.gadd_host = nullptr;
+      ps.gadd_dev = nullptr;
+      PCMI_HIP_CHECK(hipHostMalloc((void**)&ps.gadd_host, sizeof(BnGradAdd) * n_bn, hipHostMallocDefault));
+      PCMI_HIP_CHECK(hipMalloc((void**)&ps.gadd_dev, sizeof(BnGradAdd) * n_bn));
+      ps.gadd_cap = n_bn;
+    }
+    if (!ps.gadd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.gadd_copied, hipEventDisableTiming));
+    PCMI_HIP_CHECK(hipEventSynchronize(ps.gadd_copied));  // the previous table has left the pinned buffer
+    ps.gadd_n = 0;
+    ps.gadd_mark.assign(n_buckets + 1, 0);
+    while ((int)ps.bucket_ev.size() < n_buckets + 1) {
+      hipEvent_t e;
+      PCMI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ps.bucket_ev.push_back(e);
+    }
+  }
+  size_t slot_off = 0;
+  int gadd_applied = 0;  // PRIMARY: entries of the peer's table already added to grads
+  // ---- weight-gradient stream ------------------------------------------------------------------------
+  static const bool side_enabled = [] {
+    const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
+    return !(e && e[0] == '0');
+  }();
+  hipStream_t wst = st;
+  DevBuf* wws = &ps.ws;
+  if (side_enabled || job.role != BackwardJob::SOLO) {
+    rc = ensure_streams(n);
+    if (rc) return rc;
+    rc = n.ws_side.reserve(ps.ws.cap, n.side);
+    if (rc) return rc;
+    wst = n.side;
+    wws = &n.ws_side;
+  }
+  bool side_pending = false;
+  auto join_side = [&]() -> int {  // `st` continues only after the weight gradients enqueued so far
+    if (!side_pending) return PCMI_OK;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_side, n.side));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side, 0));
+    side_pending = false;
+    return PCMI_OK;
+  };
+  if (primary && peer->gadd_n > 0) {  // the peer's table (built while its backward was enqueued) -> device
+    PCMI_HIP_CHECK(hipMemcpyAsync(peer->gadd_dev, peer->gadd_host, sizeof(BnGradAdd) * peer->gadd_n, hipMemcpyHostToDevice, st));
+    PCMI_HIP_CHECK(hipEventRecord(peer->gadd_copied, st));
+  }
+  // everything the DEFERRED peer contributes to bucket q (q == n_buckets: to the whole backward) is in `grads`
+  auto absorb_peer = [&](int q) -> int {
+    side_pending = true;  // the peer's weight gradients sit on the side stream ahead of ours
+    int r = join_side();
+    if (r) return r;
+    PCMI_HIP_CHECK(hipStreamWaitEvent(st, peer->bucket_ev[q], 0));
+    const int upto = peer->gadd_mark[q];
+    if (upto > gadd_applied) {
+      bn_grad_add_kernel<<<upto - gadd_applied, 256, 0, st>>>(peer->gadd_dev + gadd_applied);
+      PCMI_LAUNCH_CHECK();
+      gadd_applied = upto;
+    }
+    return PCMI_OK;
+  };
+  // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
+  std::vector<int> bucket_last(n_buckets, -1);
+  auto bucket_of = [&](int64_t offp) {
+    int b = 0;
+    for (int q = 0; q < n_buckets; ++q)
+      if (offp >= bucket_lo_host[q]) b = q;
+    return b;
+  };
+  for (int i = n_ops - 1; i >= 0 && n_buckets > 0; --i) {
+    const auto& op = n.ops[i];
+    if (op.type == PCMI_OP_L2NORM) continue;
+    bucket_last[bucket_of(op.w_off)] = i;
+    if (op.type == PCMI_OP_BN || op.has_bias) bucket_last[bucket_of(op.b_off)] = i;
+  }
+  for (int i = n_ops - 1; i >= 0; --i) {
+    const auto& op = n.ops[i];
+    const OpPlan& pl = n.plan[i];
+    const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
+    const View dy = grad_view(n, ps, op.out, d_out, d_ld);
+    const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
+    if (op.type == PCMI_OP_CONV) {
+      const pcmi_kmap_t* map = ps.has_map[i] ? &ps.maps[i] : nullptr;
+      if (wst != st) {  // dy is complete at this point of `st` (all its consumers were differentiated before)
+        PCMI_HIP_CHECK(hipEventRecord(n.ev_main, st));
+        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main, 0));
+        side_pending = true;
+      }
+      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
+                                  grads + op.w_off, op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
+      if (rc) return rc;
+      if (op.in != n.input_tensor) {
+        const View dx = grad_view(n, ps, op.in, d_out, d_ld);
+        rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
+                                  n_in, pl.acc_in, ps.ws.p, ps.ws.cap, st);
+      }
+    } else if (op.type == PCMI_OP_BN) {
+      const View dx = grad_view(n, ps, op.in, d_out, d_ld);
+      View dr = {nullptr, 0};
+      if (op.in2 >= 0) dr = grad_view(n, ps, op.in2, d_out, d_ld);
+      const float* stats = (const float*)(ps.act.p + ps.stat_off[i]);
+      float* dgamma = scratch_g;
+      float* dbeta = scratch_g + op.cout;
+      float* acc_g = grads + op.w_off;
+      float* acc_b = grads + op.b_off;
+      if (deferred) {
+        dgamma = (float*)(ps.bn_slots.p + slot_off);
+        dbeta = dgamma + op.cout;
+        slot_off += align_up((size_t)2 * op.cout * sizeof(float), 256);
+        ps.gadd_host[ps.gadd_n++] = {acc_g, acc_b, dgamma, op.cout};
+        acc_g = acc_b = nullptr;
+      }
+      rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats,
+                       stats + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps.ws.p,
+                       ps.ws.cap, st);
+    } else {
+      const View dx = grad_view(n, ps, op.in, d_out, d_ld);
+      rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps.act.p + ps.stat_off[i]), n_in, op.cout, dx.p, dx.ld,
+                           (pcmi_stream_t)st);
+    }
+    if (rc) return rc;
+    for (int b = 0; b < n_buckets; ++b)
+      if (bucket_last[b] == i) {
+        if (deferred) {  // mark how far this pass got: chain event + number of BN slots written
+          ps.gadd_mark[b] = ps.gadd_n;
+          PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[b], st));
+        } else if (ready) {
+          rc = primary ? absorb_peer(b) : join_side();
+          if (rc) return rc;
+          ready(ready_ctx, b);
+        }
+      }
+  }
+  if (deferred) {
+    ps.gadd_mark[n_buckets] = ps.gadd_n;
+    PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[n_buckets], st));
+  } else {
+    // the gradient arena / grads are reused by whatever `st` runs next
+    rc = primary ? absorb_peer(n_buckets) : join_side();
+    if (rc) return rc;
+    if (primary) peer->valid = false;
+  }
+  if (!deferred) ps.valid = false;
+  return PCMI_OK;
 }
 
 }  // namespace pcmi
@@ -223,8 +500,8 @@ int pcmi_net_destroy(pcmi_net_t* net) {
 
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
-  size_t b = net->grad.cap + net->ws.cap + net->ws_side.cap + net->small.cap;
-  for (auto& p : net->passes) b += p.act.cap + p.ws.cap;
+  size_t b = net->ws_side.cap;
+  for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap + p.bn_slots.cap;
   *bytes = b;
   return PCMI_OK;
 }
@@ -239,6 +516,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   PassState& ps = n.passes[pass];
   ps.valid = false;
   const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
+  g_prof_fwd.start();
   // ---- level sizes (cache hits once the coordinate plan exists) ------------------------------------
   std::vector<int> keys(n.n_levels, 0);
   ps.rows.assign(n.n_levels, 0);
@@ -252,6 +530,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     rc = pcmi_coords_stride(coords, keys[l - 1], 2, &keys[l], &ps.rows[l], stream);
     if (rc) return rc;
   }
+  g_prof_fwd.lap(0);
   // ---- maps, arena layout, workspace --------------------------------------------------------------
   ps.maps.resize(n_ops);
   ps.has_map.assign(n_ops, 0);
@@ -277,6 +556,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     }
     ws_need = std::max(ws_need, op_workspace(op, ps.rows[li], ps.rows[lo], M));
   }
+  g_prof_fwd.lap(1);
   ps.tensor_off.assign(n_t, 0);
   size_t off = 0;
   for (int t = 0; t < n_t; ++t) {
@@ -294,8 +574,6 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   rc = ps.act.reserve(off, st);
   if (rc) return rc;
   rc = ps.ws.reserve(ws_need + 256, st);
-  if (rc) return rc;
-  rc = n.ws.reserve(ws_need + 256, st);  // backward (main chain); the side stream sizes its own from this one
   if (rc) return rc;
   const bool train = (training & 1) != 0, defer = train && (training & PCMI_NET_DEFER_RUNNING_STATS) != 0;
   ps.upd_n = 0;
@@ -319,6 +597,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.out_feats = out_feats;
   ps.out_ld = out_ld;
   ps.coords = coords;
+  g_prof_fwd.lap(2);
   // ---- run --------------------------------------------------------------------------------------
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
@@ -346,11 +625,15 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), stream);
     }
     if (rc) return rc;
+    g_prof_fwd.lap(op.type == PCMI_OP_CONV ? 3 : (op.type == PCMI_OP_BN ? 4 : 5));
   }
   if (defer && ps.upd_n > 0) {
     PCMI_HIP_CHECK(hipMemcpyAsync(ps.upd_dev, ps.upd_host, sizeof(BnRunningUpdate) * ps.upd_n, hipMemcpyHostToDevice, st));
     PCMI_HIP_CHECK(hipEventRecord(ps.upd_copied, st));
   }
+  g_prof_fwd.lap(6);
+  static const char* const kFwdNames[] = {"levels", "maps", "layout+reserve", "conv", "bn", "l2norm", "tail"};
+  g_prof_fwd.report("net_forward", kFwdNames, 7);
   ps.valid = train;
   return PCMI_OK;
 }
@@ -369,113 +652,43 @@ int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_l
   PCMI_REQUIRE(net && d_out && params && grads, PCMI_ERR_INVALID, "net_backward: null argument");
   PCMI_REQUIRE(pass >= 0 && pass < (int)net->passes.size() && net->passes[pass].valid, PCMI_ERR_INVALID,
                "net_backward: pass %d has no training-mode forward to differentiate", pass);
-  hipStream_t st = as_stream(stream);
+  BackwardJob job;
+  job.pass = pass;
+  job.d_out = d_out;
+  job.d_ld = d_ld;
+  job.st = as_stream(stream);
+  job.role = BackwardJob::SOLO;
+  return run_backward(*net, job, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
+}
+
+int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, const float* d_out1, int64_t d_ld1,
+                           const float* params, float* grads, const int64_t* bucket_lo_host, int n_buckets,
+                           pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream) {
+  PCMI_REQUIRE(net && d_out0 && d_out1 && params && grads, PCMI_ERR_INVALID, "net_backward_pair: null argument");
+  PCMI_REQUIRE(net->passes.size() >= 2 && net->passes[0].valid && net->passes[1].valid, PCMI_ERR_INVALID,
+               "net_backward_pair: passes 0 and 1 need a training-mode forward each");
   pcmi_net& n = *net;
-  PassState& ps = n.passes[pass];
-  const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
-  // gradient arena layout for this pass's row counts
-  n.grad_off.assign(n_t, 0);
-  size_t off = 0;
-  int max_c = 4;
-  for (int t = 0; t < n_t; ++t) {
-    max_c = std::max(max_c, n.tensors[t].channels);
-    if (n.tensors[t].parent >= 0 || t == n.input_tensor || t == n.output_tensor) continue;
-    n.grad_off[t] = off;
-    off += align_up((size_t)ps.rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
-  }
-  int rc = n.grad.reserve(off, st);
+  hipStream_t st = as_stream(stream);
+  int rc = ensure_streams(n);
   if (rc) return rc;
-  rc = n.small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
+  // pass 1 on the executor's second chain stream, after whatever `st` holds now (d_out1, the zero-filled grads)
+  PCMI_HIP_CHECK(hipEventRecord(n.ev_fork, st));
+  PCMI_HIP_CHECK(hipStreamWaitEvent(n.chain1, n.ev_fork, 0));
+  BackwardJob j1;
+  j1.pass = 1;
+  j1.d_out = d_out1;
+  j1.d_ld = d_ld1;
+  j1.st = n.chain1;
+  j1.role = BackwardJob::DEFERRED;
+  rc = run_backward(n, j1, params, grads, bucket_lo_host, n_buckets, nullptr, nullptr);
   if (rc) return rc;
-  float* scratch_g = (float*)n.small.p;
-  static const bool side_enabled = [] {
-    const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
-    return !(e && e[0] == '0');
-  }();
-  hipStream_t wst = st;  // stream of the weight-gradient kernels
-  pcmi::DevBuf* wws = &n.ws;
-  if (side_enabled) {
-    if (!n.side) {
-      PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking));
-      PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main, hipEventDisableTiming));
-      PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side, hipEventDisableTiming));
-    }
-    rc = n.ws_side.reserve(n.ws.cap, n.side);
-    if (rc) return rc;
-    wst = n.side;
-    wws = &n.ws_side;
-  }
-  bool side_pending = false;
-  auto join_side = [&]() -> int {  // `st` continues only after the weight gradients enqueued so far
-    if (!side_pending) return PCMI_OK;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_side, n.side));
-    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side, 0));
-    side_pending = false;
-    return PCMI_OK;
-  };
-  // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
-  std::vector<int> bucket_last(std::max(n_buckets, 0), -1);
-  auto bucket_of = [&](int64_t offp) {
-    int b = 0;
-    for (int q = 0; q < n_buckets; ++q)
-      if (offp >= bucket_lo_host[q]) b = q;
-    return b;
-  };
-  if (ready && n_buckets > 0) {
-    for (int i = n_ops - 1; i >= 0; --i) {
-      const auto& op = n.ops[i];
-      if (op.type == PCMI_OP_L2NORM) continue;
-      bucket_last[bucket_of(op.w_off)] = i;
-      if (op.type == PCMI_OP_BN || op.has_bias) bucket_last[bucket_of(op.b_off)] = i;
-    }
-  }
-  for (int i = n_ops - 1; i >= 0; --i) {
-    const auto& op = n.ops[i];
-    const OpPlan& pl = n.plan[i];
-    const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
-    const View dy = grad_view(n, op.out, d_out, d_ld);
-    const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
-    if (op.type == PCMI_OP_CONV) {
-      const pcmi_kmap_t* map = ps.has_map[i] ? &ps.maps[i] : nullptr;
-      if (wst != st) {  // dy is complete at this point of `st` (all its consumers were differentiated before)
-        PCMI_HIP_CHECK(hipEventRecord(n.ev_main, st));
-        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main, 0));
-        side_pending = true;
-      }
-      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
-                                  grads + op.w_off, op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
-      if (rc) return rc;
-      if (op.in != n.input_tensor) {
-        const View dx = grad_view(n, op.in, d_out, d_ld);
-        rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
-                                  n_in, pl.acc_in, n.ws.p, n.ws.cap, st);
-      }
-    } else if (op.type == PCMI_OP_BN) {
-      const View dx = grad_view(n, op.in, d_out, d_ld);
-      View dr = {nullptr, 0};
-      if (op.in2 >= 0) dr = grad_view(n, op.in2, d_out, d_ld);
-      const float* stats = (const float*)(ps.act.p + ps.stat_off[i]);
-      rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats,
-                       stats + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, scratch_g + op.cout,
-                       grads + op.w_off, grads + op.b_off, n.ws.p, n.ws.cap, st);
-    } else {
-      const View dx = grad_view(n, op.in, d_out, d_ld);
-      rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps.act.p + ps.stat_off[i]), n_in, op.cout, dx.p, dx.ld,
-                           stream);
-    }
-    if (rc) return rc;
-    if (ready)
-      for (int b = 0; b < n_buckets; ++b)
-        if (bucket_last[b] == i) {
-          rc = join_side();
-          if (rc) return rc;
-          ready(ready_ctx, b);
-        }
-  }
-  rc = join_side();  // the gradient arena / grads are reused by whatever `st` runs next
-  if (rc) return rc;
-  ps.valid = false;
-  return PCMI_OK;
+  BackwardJob j0;
+  j0.pass = 0;
+  j0.d_out = d_out0;
+  j0.d_ld = d_ld0;
+  j0.st = st;
+  j0.role = BackwardJob::PRIMARY;
+  return run_backward(n, j0, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
 }
 
 }  // extern "C"

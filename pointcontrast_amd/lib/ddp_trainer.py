@@ -16,6 +16,8 @@ checkpoint layout (:151-169) -- with these deliberate differences:
 """
 import logging
 import os
+import threading
+import time
 
 import numpy as np
 import torch
@@ -79,6 +81,8 @@ class ContrastiveLossTrainer:
     # misc.engine: "native" = whole forward / backward as one libpcmi call each (engine.py);
     #              "autograd" = per-layer torch.autograd.Function path (same kernels)
     self.engine = None
+    self.host_ms, self._host_t, self._host_c = {}, 0.0, 0.0
+    self._prefetch_thread, self._prefetch_err = None, None
     if config.misc.get("engine", "native") == "native":
       from ..engine import NativeEngine
       self.engine = NativeEngine(model, self.flat, in_channels=num_feats)
@@ -158,6 +162,13 @@ class ContrastiveLossTrainer:
     pass
 
   def _next_prepared(self, data_loader_iter, data_timer, draws):
+    th = getattr(self, "_prefetch_thread", None)
+    if th is not None:  # batch prepared by the helper thread while the previous step was being enqueued
+      th.join()
+      self._prefetch_thread = None
+      err, self._prefetch_err = self._prefetch_err, None
+      if err is not None:
+        raise err
     nxt = getattr(self, "_prefetched", None)
     self._prefetched = None
     if nxt is not None and draws is None:
@@ -167,8 +178,35 @@ class ContrastiveLossTrainer:
     data_time = data_timer.toc(average=False)
     return self._prepare(input_dict, draws), data_time
 
+  def _prefetch_worker(self, input_dict):
+    try:
+      torch.cuda.set_device(self.cur_device)
+      self._prefetched = self._prepare(input_dict)
+    except BaseException as e:  # re-raised on the training thread by _next_prepared
+      self._prefetch_err = e
+
+  def _prefetch_start(self, data_loader_iter, draws):
+    """misc.prefetch_thread: the next batch's uploads / coordinate planning (host-synchronous on the plan stream:
+    ~10 ms of waiting per batch) run on a helper thread WHILE this step is enqueued, instead of after it.  The C
+    calls release the GIL; the helper only touches its own coordinate handles and the plan stream."""
+    if draws is None and self.config.misc.get("prefetch", True) and self.config.misc.get("prefetch_thread", True):
+      self._prefetch_err = None
+      th = threading.Thread(target=self._prefetch_worker, args=(next(data_loader_iter),), daemon=True)
+      th.start()
+      self._prefetch_thread = th
+
+  def _host_mark(self, phase):
+    """Host-clock phase accounting (misc.host_profile=True): where the enqueueing thread spends an iteration."""
+    if not self.config.misc.get("host_profile", False):
+      return
+    now, cpu = time.perf_counter(), time.thread_time()
+    if phase is not None:  # wall clock, and CPU time of this thread (wall - cpu = blocked, e.g. on a full queue)
+      self.host_ms[phase] = self.host_ms.get(phase, 0.0) + (now - self._host_t) * 1e3
+      self.host_ms[phase + "_cpu"] = self.host_ms.get(phase + "_cpu", 0.0) + (cpu - self._host_c) * 1e3
+    self._host_t, self._host_c = now, cpu
+
   def _prefetch(self, data_loader_iter, draws):
-    if draws is None and self.config.misc.get("prefetch", True):
+    if draws is None and self.config.misc.get("prefetch", True) and not self.config.misc.get("prefetch_thread", True):
       self._prefetched = self._prepare(next(data_loader_iter))
 
   def _forward_pair(self, prep):
@@ -188,8 +226,11 @@ class ContrastiveLossTrainer:
     loss.backward()  # autograd path: through both networks; engine path: only down to F0 / F1
     if self.engine is not None:
       F0, F1 = self._feats
-      self.engine.backward(1, F1.grad)
-      self.engine.backward(0, F0.grad, reducer=self.reducer)  # last pass: buckets become final -> RCCL
+      if self.config.misc.get("concurrent_backward", False):
+        self.engine.backward_pair(F0.grad, F1.grad, reducer=self.reducer)  # buckets final once both passes are in
+      else:
+        self.engine.backward(1, F1.grad)
+        self.engine.backward(0, F0.grad, reducer=self.reducer)  # last pass: buckets become final -> RCCL
       self._feats = None
     self.reducer.finish()
     if self.world_size > 1 or self.reducer.active:
@@ -267,6 +308,7 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
     self.optimizer.zero_grad()
     total_timer.tic()
     prep, data_time = self._next_prepared(data_loader_iter, data_timer, draws)
+    self._prefetch_start(data_loader_iter, draws)
     F0, F1 = self._forward_pair(prep)
     pos_loss, neg_loss = self.contrastive_hardest_negative_loss(
         F0, F1, prep["input"]["correspondences"],
@@ -324,15 +366,23 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
   def _train_iter(self, data_loader_iter, timers, draws=None):
     self.model.train()
     data_meter, data_timer, total_timer = timers
+    mark = self._host_mark
+    mark(None)
     self.optimizer.zero_grad()
     total_timer.tic()
     prep, data_time = self._next_prepared(data_loader_iter, data_timer, draws)
+    self._prefetch_start(data_loader_iter, draws)
+    mark("next_prepared")
     F0, F1 = self._forward_pair(prep)
+    mark("forward")
     q = PF.GatherRowsFunction.apply(F0, prep["q_idx"])
     k = PF.GatherRowsFunction.apply(F1, prep["k_idx"])
     loss = PF.NCELossFunction.apply(q, k, self.T)
+    mark("loss")
     result = self._backward_and_step(loss, {"loss": loss.detach()})
+    mark("backward_step")
     self._prefetch(data_loader_iter, draws)
+    mark("prefetch")
     total_timer.toc()
     data_meter.update(data_time)
     return result

@@ -549,10 +549,12 @@ def test_engine_matches_autograd_path(ME, name, crop, batch):
   for k, v in dev.state_dict().items():
     if "running" in k:
       assert_close(v, rs_after[k], 1e-5, "forward_pair " + k)
+  g_seq = flat.g.clone()  # of the two sequential engine backwards above
   flat.zero_grad()
-  eng.backward(1, g[1])
-  eng.backward(0, g[0])
+  eng.backward_pair(g[0], g[1])  # both backwards next to each other: same sums in the same order
   torch.cuda.synchronize()
+  assert torch.equal(flat.g, g_seq), "backward_pair differs from backward(1); backward(0): max |diff| %.3e" % float(
+      (flat.g - g_seq).abs().max())
 
 
 @pytest.mark.parametrize("which", ["nce", "hardest"])
