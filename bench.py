@@ -22,6 +22,9 @@ Rank 0 prints ONE JSON line; besides the contract keys it carries
 import argparse
 import json
 import os
+
+# compute, plan, pair-forward, weight-gradient and RCCL streams should each get a hardware queue (ROCm default: 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import time
 
@@ -300,6 +303,7 @@ def main():
                                % (1 if args.loss == "nce" else 2, args.model, args.loss, args.voxel, args.batch, n0, n1),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine, "final_loss": round(loss_val, 5),
                    "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
+                   **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),
                    **({"host_phase_ms_per_step": {k: round(v / (args.steps + args.warmup), 3) for k, v in trainer.host_ms.items()}}
                       if trainer.host_ms else {}),
                    "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3)},

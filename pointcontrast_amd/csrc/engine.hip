@@ -231,7 +231,6 @@ static int ensure_streams(pcmi_net& n) {
   const char* pe = getenv("PCMI_WGRAD_PRIORITY");
   const int prio = (pe && pe[0] == '0') ? 0 : least;
   PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio));
-  PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.chain1, hipStreamNonBlocking));
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main, hipEventDisableTiming));
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side, hipEventDisableTiming));
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
@@ -671,6 +670,7 @@ int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, 
   hipStream_t st = as_stream(stream);
   int rc = ensure_streams(n);
   if (rc) return rc;
+  if (!n.chain1) PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.chain1, hipStreamNonBlocking));  // only if ever used
   // pass 1 on the executor's second chain stream, after whatever `st` holds now (d_out1, the zero-filled grads)
   PCMI_HIP_CHECK(hipEventRecord(n.ev_fork, st));
   PCMI_HIP_CHECK(hipStreamWaitEvent(n.chain1, n.ev_fork, 0));

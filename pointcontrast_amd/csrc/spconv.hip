@@ -483,7 +483,12 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair) {
     p.NT = (nt_all % 2 == 0) ? 2 : 1;
   if (!pair && K > 1) {
     const int64_t wgs = ceil_div(rows, 32 * p.RW) * (nt_all / p.NT);
-    const int64_t target = (5 * (int64_t)num_cu()) / 2;
+    static const int target_x10 = [] {  // workgroups aimed at, in tenths of a CU count (experiments: PCMI_KSPLIT_TARGET)
+      const char* e = getenv("PCMI_KSPLIT_TARGET");
+      const int v = e ? atoi(e) : 0;
+      return v > 0 ? v : 25;
+    }();
+    const int64_t target = (target_x10 * (int64_t)num_cu()) / 10;
     if (wgs < target) p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
   }
   return p;

@@ -6,6 +6,9 @@
 Overrides use the reference's ``group.key=value`` syntax (scripts/ddp_local.sh)."""
 import logging
 import os
+
+# compute, plan, pair-forward, weight-gradient and RCCL streams should each get a hardware queue (ROCm default: 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 
 import numpy as np

@@ -83,6 +83,7 @@ class ContrastiveLossTrainer:
     self.engine = None
     self.host_ms, self._host_t, self._host_c = {}, 0.0, 0.0
     self._prefetch_thread, self._prefetch_err = None, None
+    self._gpu_marks = []
     if config.misc.get("engine", "native") == "native":
       from ..engine import NativeEngine
       self.engine = NativeEngine(model, self.flat, in_channels=num_feats)
@@ -196,7 +197,12 @@ class ContrastiveLossTrainer:
       self._prefetch_thread = th
 
   def _host_mark(self, phase):
-    """Host-clock phase accounting (misc.host_profile=True): where the enqueueing thread spends an iteration."""
+    """Host-clock phase accounting (misc.host_profile=True): where the enqueueing thread spends an iteration.
+    With misc.gpu_profile=True the same marks also drop timing events into the compute stream (gpu_phase_ms())."""
+    if self.config.misc.get("gpu_profile", False):
+      ev = torch.cuda.Event(enable_timing=True)
+      ev.record()
+      self._gpu_marks.append((phase, ev))
     if not self.config.misc.get("host_profile", False):
       return
     now, cpu = time.perf_counter(), time.thread_time()
@@ -204,6 +210,21 @@ class ContrastiveLossTrainer:
       self.host_ms[phase] = self.host_ms.get(phase, 0.0) + (now - self._host_t) * 1e3
       self.host_ms[phase + "_cpu"] = self.host_ms.get(phase + "_cpu", 0.0) + (cpu - self._host_c) * 1e3
     self._host_t, self._host_c = now, cpu
+
+  def gpu_phase_ms(self, skip=0):
+    """Stream time between consecutive marks, averaged over the recorded iterations (after a synchronize)."""
+    acc, cnt, prev, it = {}, {}, None, 0
+    for phase, ev in self._gpu_marks:
+      if phase is None:
+        it += 1
+        if prev is not None and it > skip + 1:
+          acc["(between iterations)"] = acc.get("(between iterations)", 0.0) + prev.elapsed_time(ev)
+          cnt["(between iterations)"] = cnt.get("(between iterations)", 0) + 1
+      elif it > skip:
+        acc[phase] = acc.get(phase, 0.0) + prev.elapsed_time(ev)
+        cnt[phase] = cnt.get(phase, 0) + 1
+      prev = ev
+    return {k: round(acc[k] / cnt[k], 3) for k in acc}
 
   def _prefetch(self, data_loader_iter, draws):
     if draws is None and self.config.misc.get("prefetch", True) and not self.config.misc.get("prefetch_thread", True):
