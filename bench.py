@@ -322,7 +322,14 @@ def main():
       traffic = None
       try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-          traffic = json.load(f)["bytes_per_launch"].get("spconv_mfma_kernel<3, 4, false, false, 2>")
+          per_launch = json.load(f)["bytes_per_launch"]
+        # the unit-balanced launch of this conv = main kernel + fix-up kernel (in pmc_probe.py only the 96->96 conv
+        # takes that launch, so the fix-up's per-launch average belongs to this shape)
+        traffic = per_launch.get("spconv_mfma_kernel<3, 4, false, false, 2, true>")
+        if traffic is not None:
+          traffic += per_launch.get("sk_fixup_kernel", 0.0)
+        else:
+          traffic = per_launch.get("spconv_mfma_kernel<3, 4, false, false, 2, false>")
       except (OSError, ValueError, KeyError):
         pass
       out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],

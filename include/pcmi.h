@@ -118,6 +118,12 @@ typedef struct pcmi_kmap {
    * perm[i] = row handled at position i; nbr_perm[k][i] = nbr[k][perm[i]].  Results are unaffected. */
   const int32_t* perm;
   const int32_t* nbr_perm;
+  /* Work units of the 128-row tiles of that order (NULL when perm is NULL): tile_mask[t] = OR of the occupancy
+   * masks of the tile's rows, tile_pref[t] = number of (tile, occupied offset) units before tile t
+   * (tile_pref[n_tiles] = total).  Lets the conv kernel give every workgroup the same number of units. */
+  const uint32_t* tile_mask;
+  const int32_t* tile_pref;
+  int64_t n_tiles;
 } pcmi_kmap_t;
 
 /* Host-side enumeration of the kernel offsets in weight-slice order

@@ -33,6 +33,7 @@ class KMap(C.Structure):
       ("nbr", c_vp), ("pair_in", c_vp), ("pair_out", c_vp), ("offs", c_vp),
       ("offs_host", c_i64 * (MAX_K + 1)), ("mirror", c_i32 * MAX_K),
       ("perm", c_vp), ("nbr_perm", c_vp),
+      ("tile_mask", c_vp), ("tile_pref", c_vp), ("n_tiles", c_i64),
   ]
 
 

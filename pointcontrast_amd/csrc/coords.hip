@@ -695,6 +695,9 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
   m.M = m.offs_host[K];
   m.perm = nullptr;
   m.nbr_perm = nullptr;
+  m.tile_mask = nullptr;
+  m.tile_pref = nullptr;
+  m.n_tiles = 0;
   if (stride == 1 && n_out >= kSortRowsMin) {
     int32_t* perm = h->persistent.alloc_n<int32_t>(n_out);
     int32_t* nbr_perm = h->persistent.alloc_n<int32_t>(tot);
@@ -708,6 +711,16 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
     if (rc) return rc;
     m.perm = perm;
     m.nbr_perm = nbr_perm;
+    const int64_t n_tiles = ceil_div(n_out, 128);
+    uint32_t* tile_mask = h->persistent.alloc_n<uint32_t>(n_tiles);
+    int32_t* tile_pref = h->persistent.alloc_n<int32_t>(n_tiles + 1);
+    int32_t* tile_cnt = h->scratch.alloc_n<int32_t>(n_tiles);
+    if (!tile_mask || !tile_pref || !tile_cnt) return PCMI_ERR_HIP;
+    rc = tile_units(mk_out, K, n_out, tile_mask, tile_cnt, tile_pref, st);
+    if (rc) return rc;
+    m.tile_mask = tile_mask;
+    m.tile_pref = tile_pref;
+    m.n_tiles = n_tiles;
   }
   m.nbr = nbr;
   m.pair_in = pair_in;

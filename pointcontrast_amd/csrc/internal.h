@@ -36,6 +36,8 @@ int bn_running_update(const BnRunningUpdate* table_dev, int n_entries, hipStream
 size_t sort_rows_temp_bytes(int64_t n);
 int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, uint32_t* mask_in, uint32_t* mask_out,
                       int32_t* iota, void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st);
+int tile_units(const uint32_t* sorted_key, int K, int64_t n, uint32_t* tile_mask, int32_t* cnt, int32_t* tile_pref,
+               hipStream_t st);
 // rows of the contiguous tile range one XCD processes (tile swizzle of the conv kernel, 128-row tiles)
 static inline int64_t xcd_chunk_rows(int64_t n) { return ceil_div(ceil_div(n, 128), 8) * 128; }
 

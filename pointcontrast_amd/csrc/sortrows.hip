@@ -34,6 +34,60 @@ __global__ void permute_table_kernel(const int32_t* __restrict__ nbr, int K, int
   nbr_perm[idx] = nbr[k * n + perm[i]];
 }
 
+// tile_mask[t] = OR of the masks of the 128 rows at sorted positions [128 t, 128 t + 128), cnt[t] = its popcount
+__global__ __launch_bounds__(128) void tile_mask_kernel(const uint32_t* __restrict__ sorted_key, int K, int64_t n,
+                                                        uint32_t* __restrict__ tile_mask, int32_t* __restrict__ cnt) {
+  __shared__ uint32_t s_m[2];
+  const int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x;
+  uint32_t m = i < n ? (sorted_key[i] & ((1u << K) - 1u)) : 0u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) m |= __shfl_xor(m, d, 64);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = s_m[0] | s_m[1];
+    tile_mask[blockIdx.x] = m;
+    cnt[blockIdx.x] = __popc(m);
+  }
+}
+
+// pref[t] = sum of cnt[0..t), pref[n_tiles] = total; one workgroup (a level has at most a few thousand tiles)
+__global__ __launch_bounds__(1024) void tile_prefix_kernel(const int32_t* __restrict__ cnt, int64_t n_tiles,
+                                                           int32_t* __restrict__ pref) {
+  __shared__ int32_t s_sum[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n_tiles + 1023) / 1024;
+  const int64_t b = (int64_t)t * per, e = b + per < n_tiles ? b + per : n_tiles;
+  int32_t s = 0;
+  for (int64_t i = b; i < e; ++i) s += cnt[i];
+  s_sum[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the per-thread sums
+    const int32_t v = t >= d ? s_sum[t - d] : 0;
+    __syncthreads();
+    s_sum[t] += v;
+    __syncthreads();
+  }
+  int32_t run = t > 0 ? s_sum[t - 1] : 0;
+  for (int64_t i = b; i < e; ++i) {
+    pref[i] = run;
+    run += cnt[i];
+  }
+  if (t == 1023) pref[n_tiles] = s_sum[1023];
+}
+
+// sorted_key: the keys sort_rows_by_mask left in mask_out.  cnt: scratch [n_tiles].
+int tile_units(const uint32_t* sorted_key, int K, int64_t n, uint32_t* tile_mask, int32_t* cnt, int32_t* tile_pref,
+               hipStream_t st) {
+  const int64_t n_tiles = ceil_div(n, 128);
+  if (n_tiles == 0) return PCMI_OK;
+  tile_mask_kernel<<<dim3((unsigned)n_tiles), 128, 0, st>>>(sorted_key, K, n, tile_mask, cnt);
+  PCMI_LAUNCH_CHECK();
+  tile_prefix_kernel<<<1, 1024, 0, st>>>(cnt, n_tiles, tile_pref);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
 size_t sort_rows_temp_bytes(int64_t n) {
   size_t bytes = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,

@@ -64,6 +64,11 @@ struct ConvArgs {
   const float* bias;     // nullable, only when ksplit == 1
   int xcd_tiles;         // > 0: tiles per XCD of the XCD-contiguous tile order (grid.x = 8 * xcd_tiles)
   int accumulate;        // out += result instead of out = result (only when ksplit == 1)
+  // unit-balanced mode (SK kernels): see spconv_mfma_kernel
+  const uint32_t* sk_mask;  // [n_tiles] occupied offsets of a tile
+  const int32_t* sk_pref;   // [n_tiles + 1] units before a tile
+  int sk_tiles;
+  float* sk_part;           // [gridDim.x][2][128][N] partial tiles
 };
 
 // Weight chunk [32 x 32*NT] global -> registers -> LDS.  WT: B[c][n] = W[n][c] (backward-data).
@@ -103,7 +108,14 @@ __device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT], float* __res
   }
 }
 
-template <int NT, int RW, bool WT, bool PAIR, int DEPTH>
+// SK ("stream-K" over the offsets): a tile's cost is proportional to the number of offsets that occur in it (9..27
+// after the mask sort), and 683 tiles on 768 resident workgroup slots is ONE round whose length the unluckiest CU
+// sets -- the waves were alive for 68 % of the kernel.  In SK mode the launch is a fixed set of resident workgroups;
+// the (tile, occupied offset) units of the whole level are numbered tile-major (map.tile_pref) and workgroup g
+// takes units [g*per, (g+1)*per): whole tiles are written as usual, the at most two tiles a workgroup shares
+// with its neighbours go to partial slots [g][0 = its first piece | 1 = its last piece] and
+// sk_fixup_kernel adds the pieces of a split tile in workgroup order (deterministic).
+template <int NT, int RW, bool WT, bool PAIR, int DEPTH, bool SK = false>
 // min 3 waves/SIMD: with this bound hipcc keeps the accumulators in plain VGPRs (<= 158 in total, no scratch);
 // without it it split them into AGPRs at 170-220 registers total and 2 waves/SIMD
 __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
@@ -121,15 +133,43 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   __shared__ int32_t s_idx[KSLOTS][TM];
   __shared__ int32_t s_orow[TM];
   __shared__ int32_t s_klist[KSLOTS];
+  __shared__ int32_t s_kabs[KSLOTS];  // offset index of a slot (weight slice = wsel[s_kabs])
   __shared__ int32_t s_nk;
   __shared__ int64_t s_tile[2];
 
-  const int t = threadIdx.x;
+  const int n0 = blockIdx.y * NS;
+
+  // ---- unit range of this workgroup (SK) ------------------------------------------------------
+  int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
+  bool sk_first = true;
+  if constexpr (SK) {
+    const int G = (int)gridDim.x;  // multiple of 8: workgroup b (on XCD b % 8) -> logical g in that XCD's range
+    sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
+    const int U = a.sk_pref[a.sk_tiles];
+    const int per = (U + G - 1) / G;
+    sk_u = sk_g * per;
+    sk_u1 = min(U, sk_u + per);
+    if (sk_u >= sk_u1) return;
+    if (threadIdx.x == 0) {  // last tile whose first unit is <= sk_u
+      int lo = 0, hi = a.sk_tiles - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.sk_pref[mid] <= sk_u) lo = mid; else hi = mid - 1;
+      }
+      s_tile[0] = lo;
+    }
+    __syncthreads();
+    sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);  // wave-uniform: keep the piece bookkeeping in SGPRs
+  }
+  for (;;) {  // one pass per tile piece (exactly one when !SK)
+  bool sk_whole = true;
+  int sk_next_u = 0;
+  int t = threadIdx.x;
+  // SK: opaque per pass, otherwise hipcc hoists every lane-dependent address out of the piece loop (+35 VGPRs)
+  if constexpr (SK) asm volatile("" : "+v"(t));
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int rg = wave % RW, kg = wave / RW;
-  const int n0 = blockIdx.y * NS;
-
   // ---- tile descriptor -------------------------------------------------------------------
   int k_single = 0;
   if (PAIR) {
@@ -160,6 +200,35 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
     if (t == 0) {
       s_klist[0] = 0;  // slot of s_idx; the weight slice comes from k_single
       s_nk = 1;
+    }
+  } else if constexpr (SK) {
+    // piece = offsets [jb, je) of the occupied-offset list of tile sk_tile
+    const int64_t row0 = (int64_t)sk_tile * TM;
+    const uint32_t tmask = a.sk_mask[sk_tile];
+    const int pref = a.sk_pref[sk_tile], nk_t = __popc(tmask);
+    const int jb = sk_u - pref, je = min(sk_u1 - pref, nk_t);
+    sk_whole = (jb == 0 && je == nk_t);
+    sk_next_u = pref + je;
+    if (t == 0) {
+      int j = 0, c = 0;
+      for (int k = 0; k < a.K; ++k)
+        if ((tmask >> k) & 1u) {
+          if (j >= jb && j < je) {
+            s_kabs[c] = k;
+            s_klist[c] = c;
+            ++c;
+          }
+          ++j;
+        }
+      s_nk = c;
+    }
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    __syncthreads();
+    const int cnt = je - jb;
+    for (int p = t; p < cnt * TM; p += 256) {
+      const int kk = p / TM, rr = p - kk * TM;
+      const int64_t row = row0 + rr;
+      s_idx[kk][rr] = row < a.n_rows ? a.nbr[(int64_t)s_kabs[kk] * a.n_rows + row] : -1;
     }
   } else {
     // Workgroup b is observed to run on XCD b % 8 (never relied upon for correctness): give every XCD a
@@ -214,7 +283,7 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   auto load_b = [&](int step) {
     const int kslot = s_klist[step / nch];
     const int c0 = (step % nch) * kKC;
-    const int wk = PAIR ? a.wsel[k_single] : a.wsel[kbeg_blk + kslot];
+    const int wk = PAIR ? a.wsel[k_single] : (SK ? a.wsel[s_kabs[kslot]] : a.wsel[kbeg_blk + kslot]);
     load_b_regs<NT, WT>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
   };
   auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
@@ -325,7 +394,18 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
-  if (kg == 0) {
+  if (SK && !sk_whole) {
+    // a piece of a tile shared with the neighbouring workgroups: dense [128][N] slot, summed by sk_fixup_kernel
+    if (kg == 0) {
+      float* pp = a.sk_part + ((int64_t)(2 * sk_g + (sk_first ? 0 : 1)) * TM + rg * 32) * a.N + n0 + r;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int i = (j & 3) + 8 * (j >> 2) + 4 * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) pp[(int64_t)i * a.N + nt * 32] = acc[nt][j];
+      }
+    }
+  } else if (kg == 0) {
     float* outp = a.out + (PAIR ? 0 : (int64_t)blockIdx.z * a.split_stride);
     float bv[NT];
 #pragma unroll
@@ -345,6 +425,63 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
         }
       }
     }
+  }
+  if constexpr (!SK) {
+    break;
+  } else {
+    sk_u = sk_next_u;
+    ++sk_tile;
+    sk_first = false;
+    if (sk_u >= sk_u1) break;
+    __syncthreads();  // s_idx / s_orow / the staging area are rewritten by the next piece
+  }
+  }  // for (;;)
+}
+
+// Sums the pieces of the tiles that the SK launch split between workgroups (see spconv_mfma_kernel) into the
+// output rows, in workgroup order.  One workgroup per tile; tiles written whole by one workgroup are skipped.
+__global__ __launch_bounds__(256) void sk_fixup_kernel(const float* __restrict__ part, const int32_t* __restrict__ pref,
+                                                       int n_tiles, int G, const int32_t* __restrict__ perm, int64_t n_rows,
+                                                       int N, const float* __restrict__ bias, float* __restrict__ out,
+                                                       int64_t out_ld, int accumulate) {
+  constexpr int TM = 128;
+  const int tile = blockIdx.x;
+  const int U = pref[n_tiles], per = (U + G - 1) / G;
+  const int u0 = pref[tile], u1 = pref[tile + 1];
+  if (u1 <= u0) return;
+  const int g_first = u0 / per, g_last = (u1 - 1) / per;
+  if (g_first == g_last) return;  // one workgroup had the whole tile and wrote it itself
+  const int n4 = N / 4;
+  const int64_t row0 = (int64_t)tile * TM;
+  for (int e = threadIdx.x; e < TM * n4; e += 256) {
+    const int rr = e / n4, c = (e - rr * n4) * 4;
+    const int64_t row = row0 + rr;
+    if (row >= n_rows) continue;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = g_first; g <= g_last; ++g) {
+      const int slot = (u0 <= g * per) ? 0 : 1;  // the tile holds the first unit of g: g's first piece
+      const float4 v = *reinterpret_cast<const float4*>(part + ((int64_t)(2 * g + slot) * TM + rr) * N + c);
+      sum.x += v.x;
+      sum.y += v.y;
+      sum.z += v.z;
+      sum.w += v.w;
+    }
+    if (bias) {
+      sum.x += bias[c];
+      sum.y += bias[c + 1];
+      sum.z += bias[c + 2];
+      sum.w += bias[c + 3];
+    }
+    const int64_t orow = perm ? perm[row] : row;
+    float4* dst = reinterpret_cast<float4*>(out + orow * out_ld + c);
+    if (accumulate) {
+      const float4 o = *dst;
+      sum.x += o.x;
+      sum.y += o.y;
+      sum.z += o.z;
+      sum.w += o.w;
+    }
+    *dst = sum;
   }
 }
 
@@ -433,6 +570,36 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
     spconv_mfma_kernel<NT, RW, WT, PAIR, 2><<<grid, 256, 0, st>>>(a);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
+}
+
+constexpr int kStreamKDefaultMinTiles = 256;  // unit-balanced launch from 256 tiles (32768 rows); PCMI_SPCONV_STREAMK=0 turns it off
+
+// unit-balanced launch (128-row tiles, no pair mode)
+template <bool WT>
+static int launch_sk(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  switch (NT) {
+    case 1: spconv_mfma_kernel<1, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
+    case 2: spconv_mfma_kernel<2, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
+    case 3: spconv_mfma_kernel<3, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
+    case 4: spconv_mfma_kernel<4, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
+    default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
+  }
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+// PCMI_SPCONV_STREAMK: minimum number of 128-row tiles for the unit-balanced launch (0 = never).
+static int64_t sk_min_tiles() {  // read per call: the parity test compares both launches in one process
+  const char* e = getenv("PCMI_SPCONV_STREAMK");
+  return e ? (int64_t)atoll(e) : (int64_t)kStreamKDefaultMinTiles;
+}
+static int sk_workgroups() { return 3 * num_cu() / 8 * 8; }  // resident workgroups (3 waves/SIMD), multiple of 8
+static bool sk_rows_eligible(int64_t rows, int K) {
+  const int64_t mt = sk_min_tiles();
+  return K > 1 && mt > 0 && rows >= 4096 /* kSortRowsMin: such maps carry tile units */ && ceil_div(rows, 128) >= mt;
+}
+static size_t sk_partial_bytes(int64_t rows, int N, int K) {
+  return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups() * 2 * 128 * N * sizeof(float) : 0;
 }
 
 template <int RW, bool WT, bool PAIR>
@@ -539,6 +706,10 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   a.accumulate = accumulate;
   a.out = out;
   a.out_ld = out_ld;
+  a.sk_mask = nullptr;
+  a.sk_pref = nullptr;
+  a.sk_tiles = 0;
+  a.sk_part = nullptr;
   if (pair_mode) {
     a.pair_src = swap_pairs ? map->pair_in : map->pair_out;
     a.pair_dst = swap_pairs ? map->pair_out : map->pair_in;
@@ -558,6 +729,24 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
     a.perm = map->perm;
   }
   Plan p = make_plan(n_rows, N, a.K, false);
+  // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
+  if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
+      map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64) {
+    const int G = sk_workgroups();
+    const size_t need = sk_partial_bytes(n_rows, N, a.K);
+    PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
+    a.sk_mask = map->tile_mask;
+    a.sk_pref = map->tile_pref;
+    a.sk_tiles = (int)map->n_tiles;
+    a.sk_part = (float*)ws;
+    dim3 grid((unsigned)G, (unsigned)(N / (32 * p.NT)), 1);
+    int rc = w_transposed ? launch_sk<true>(p.NT, a, grid, st) : launch_sk<false>(p.NT, a, grid, st);
+    if (rc) return rc;
+    sk_fixup_kernel<<<dim3((unsigned)a.sk_tiles), 256, 0, st>>>(a.sk_part, a.sk_pref, a.sk_tiles, G, a.perm, n_rows, N, bias,
+                                                              out, out_ld, accumulate);
+    PCMI_LAUNCH_CHECK();
+    return PCMI_OK;
+  }
   if (p.ksplit > 1) {
     const size_t need = (size_t)p.ksplit * n_rows * N * sizeof(float);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
@@ -587,7 +776,9 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
 }
 
 size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K) {
-  return std::max(partial_bytes(n_out, cout, K), partial_bytes(n_in, cin, K));
+  const size_t ks = std::max(partial_bytes(n_out, cout, K), partial_bytes(n_in, cin, K));
+  const size_t sk = n_in == n_out ? std::max(sk_partial_bytes(n_out, cout, K), sk_partial_bytes(n_in, cin, K)) : 0;
+  return std::max(ks, sk);
 }
 
 }  // namespace pcmi

@@ -36,7 +36,7 @@ for line in open(os.path.join(src, "pmc_FETCH_SIZE.log")):
     algo[line.split()[2]] = {k: int(v) for k, v in m.items()}
 rows, traffic = [], {}
 for k in F:
-  if not any(x in k for x in ("spconv_mfma", "wgrad_mfma", "eltwise_kernel<2>")):
+  if not any(x in k for x in ("spconv_mfma", "wgrad_mfma", "sk_fixup", "eltwise_kernel<2>")):
     continue
   rd = mean(F[k]["FETCH_SIZE"]) * 1024 * f_scale
   wr = mean(W[k]["WRITE_SIZE"]) * 1024 * w_scale if k in W else float("nan")

@@ -744,3 +744,30 @@ def test_full_size_conv_linearity_and_adjointness(ME, full_batch, kind, cin, cou
   scale = float(torch.sqrt(((ox.detach().double() * g.double()) ** 2).sum()))
   assert abs(float((x.detach().double() * x.grad.double()).sum() - lhs)) <= 1e-5 * scale, "bwd_data is not the adjoint of fwd"
   assert abs(float((W.detach().double() * W.grad.double()).sum() - lhs)) <= 1e-5 * scale, "bwd_weight is not the adjoint of fwd"
+
+
+@pytest.mark.parametrize("cin,cout", [(96, 96), (128, 96), (32, 32), (64, 128)])
+def test_full_size_streamk_matches_plain(ME, full_batch, cin, cout, monkeypatch):
+  """The unit-balanced launch (PCMI_SPCONV_STREAMK: tiles split along their offset lists, pieces summed by the
+  fix-up kernel) against the one-tile-per-workgroup launch on the same map: forward and backward-data."""
+  from pointcontrast_amd import functional as PF
+  C = full_batch["sinput0_C"]
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  assert m.n_tiles == -(-len(C) // 128) and m.tile_pref
+  torch.manual_seed(2)
+  W = (torch.randn(27, cin, cout, device=DEV) / (cin * 27) ** 0.5).requires_grad_(True)
+  b = torch.randn(cout, device=DEV)
+  g = torch.randn(len(C), cout, device=DEV)
+  res = {}
+  for mode in ("0", "16"):
+    monkeypatch.setenv("PCMI_SPCONV_STREAMK", mode)
+    x = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
+    y = PF.SparseConvFunction.apply(x, W, b, m, False, len(C), cm)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res[mode] = (y.detach().clone(), x.grad.clone())
+  monkeypatch.delenv("PCMI_SPCONV_STREAMK")
+  assert_close(res["16"][0], res["0"][0], 1e-5, "stream-K forward")
+  assert_close(res["16"][1], res["0"][1], 1e-5, "stream-K backward-data")
