@@ -115,7 +115,7 @@ __device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT], float* __res
 // takes units [g*per, (g+1)*per): whole tiles are written as usual, the at most two tiles a workgroup shares
 // with its neighbours go to partial slots [g][0 = its first piece | 1 = its last piece] and
 // sk_fixup_kernel adds the pieces of a split tile in workgroup order (deterministic).
-template <int NT, int RW, bool WT, bool PAIR, int DEPTH, bool SK = false>
+template <int NT, int RW, bool WT, bool PAIR, bool SK = false>
 // min 3 waves/SIMD: with this bound hipcc keeps the accumulators in plain VGPRs (<= 158 in total, no scratch);
 // without it it split them into AGPRs at 170-220 registers total and 2 waves/SIMD
 __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
@@ -287,10 +287,11 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
     load_b_regs<NT, WT>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
   };
   auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
-  // A operands live in a three-deep register ring (gathers are the long-latency loads: HBM / far-L2
-  // misses), B chunks are one step ahead through LDS (weights are L2 hits shared by every workgroup).
-  float4 a0[BPG], a1[BPG], a2[BPG];
-  bool v0 = false, v1 = false, v2 = false;
+  // A operands (gathers: the long-latency loads) and B chunks (weights: L2 hits shared by every workgroup, through
+  // LDS) are both fetched one 32-channel step ahead.  (A two-steps-ahead register ring was measured: no gain once
+  // the accumulators stayed in VGPRs, and one wave per SIMD less.)
+  float4 a0[BPG], a1[BPG];
+  bool v0 = false, v1 = false;
   auto load_a = [&](int step, float4* dst) -> bool {
     const int kslot = s_klist[step / nch];
     const int c0 = (step % nch) * kKC;
@@ -311,17 +312,12 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   if (nsteps > 0) {
     load_b(0);
     v0 = load_a(0, a0);
-    if (DEPTH == 3 && nsteps > 1) v1 = load_a(1, a1);
     store_b(0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
       const bool more = step + 1 < nsteps;
       if (more) load_b(step + 1);
-      if (DEPTH == 3) {
-        if (step + 2 < nsteps) v2 = load_a(step + 2, a2);
-      } else {
-        if (more) v1 = load_a(step + 1, a1);
-      }
+      if (more) v1 = load_a(step + 1, a1);
       if (v0) {
         // B fragments are read from LDS PF contraction steps AHEAD of the MFMAs that use them (register ring).
         // Written inline, hipcc emitted ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, i.e. the full LDS latency in
@@ -355,12 +351,8 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
       if (more) store_b((step + 1) & 1);
       __syncthreads();
 #pragma unroll
-      for (int b = 0; b < BPG; ++b) {
-        a0[b] = a1[b];
-        if (DEPTH == 3) a1[b] = a2[b];
-      }
+      for (int b = 0; b < BPG; ++b) a0[b] = a1[b];
       v0 = v1;
-      if (DEPTH == 3) v1 = v2;
     }
   }
 
@@ -546,28 +538,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
   }
 }
 
-// A-operand prefetch depth: 3 = gathers two steps ahead (more registers, 2 waves/SIMD),
-// 2 = one step ahead (3 waves/SIMD).  PCMI_SPCONV_DEPTH overrides the per-regime default.
-static int g_depth_override = -1;
-static int prefetch_depth(int RW) {
-  if (g_depth_override < 0) {
-    const char* e = getenv("PCMI_SPCONV_DEPTH");
-    g_depth_override = e ? atoi(e) : 0;
-  }
-  if (g_depth_override == 2 || g_depth_override == 3) return g_depth_override;
-  (void)RW;
-  return 0;  // per-variant default, see launch_one
-}
-
 template <int NT, int RW, bool WT, bool PAIR>
 static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  // measured on the 96->96 level-1 conv: depth 3 wins with transposed weights (0.49 vs 0.61 ms), depth 2
-  // (one more resident wave per SIMD) without (0.48 vs 0.64 ms)
-  const int d = prefetch_depth(RW);
-  if (d == 3)  // default depth 2: with the accumulators in VGPRs (launch bounds) depth 3 measured no gain
-    spconv_mfma_kernel<NT, RW, WT, PAIR, 3><<<grid, 256, 0, st>>>(a);
-  else
-    spconv_mfma_kernel<NT, RW, WT, PAIR, 2><<<grid, 256, 0, st>>>(a);
+  spconv_mfma_kernel<NT, RW, WT, PAIR><<<grid, 256, 0, st>>>(a);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -578,10 +551,10 @@ constexpr int kStreamKDefaultMinTiles = 256;  // unit-balanced launch from 256 t
 template <bool WT>
 static int launch_sk(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   switch (NT) {
-    case 1: spconv_mfma_kernel<1, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
-    case 2: spconv_mfma_kernel<2, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
-    case 3: spconv_mfma_kernel<3, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
-    case 4: spconv_mfma_kernel<4, 4, WT, false, 2, true><<<grid, 256, 0, st>>>(a); break;
+    case 1: spconv_mfma_kernel<1, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
+    case 2: spconv_mfma_kernel<2, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
+    case 3: spconv_mfma_kernel<3, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
+    case 4: spconv_mfma_kernel<4, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
     default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
   }
   PCMI_LAUNCH_CHECK();

@@ -1,6 +1,6 @@
 """Kernel micro-benchmark on the real maps of the bench batch: conv fwd / bwd-data / bwd-weight for the
 layer shapes of Res16UNet34C at every level (HIP events on the launch stream).  Usage on the GPU box:
-  PCMI_SPCONV_DEPTH=2 python scripts/kbench.py ; PCMI_SPCONV_DEPTH=3 python scripts/kbench.py"""
+  python scripts/kbench.py ; PCMI_SPCONV_STREAMK=0 python scripts/kbench.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,7 +17,7 @@ cm.plan_unet(4)
 keys = [st.coords_key]
 for _ in range(4):
   keys.append(cm.stride(keys[-1], 2))
-print("depth env", os.environ.get("PCMI_SPCONV_DEPTH"), "rows", [cm.size(k) for k in keys], flush=True)
+print("streamk env", os.environ.get("PCMI_SPCONV_STREAMK"), "rows", [cm.size(k) for k in keys], flush=True)
 tot = {}
 
 
