@@ -52,6 +52,9 @@ static HostProfile g_prof_fwd, g_prof_bwd;
 struct DevBuf {
   char* p = nullptr;
   size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;  // owns device memory
+  DevBuf& operator=(const DevBuf&) = delete;
   // grows with 25 % head-room; the old block may still be in flight (on any of the executor's streams) -> sync
   // the device before freeing it (growth happens in the first iterations only)
   int reserve(size_t bytes, hipStream_t st) {
@@ -81,6 +84,9 @@ struct OpPlan {
 struct BnGradAdd;
 
 struct PassState {
+  PassState() = default;
+  PassState(const PassState&) = delete;  // owns device / pinned memory and events
+  PassState& operator=(const PassState&) = delete;
   DevBuf act;
   DevBuf ws;  // forward workspace of this pass (passes may be forwarded concurrently on different streams)
   // deferred BatchNorm running-estimate updates of this pass (training & PCMI_NET_DEFER_RUNNING_STATS)
@@ -439,7 +445,7 @@ int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_
   n->plan.resize(n_ops);
   n->input_tensor = input_tensor;
   n->output_tensor = output_tensor;
-  n->passes.resize(n_passes);
+  n->passes = std::vector<pcmi::PassState>(n_passes);  // elements are neither copied nor moved afterwards
   auto fail = [&](const char* msg, int i) {
     set_error("net_create: %s (index %d)", msg, i);
     delete n;
