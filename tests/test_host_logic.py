@@ -129,3 +129,31 @@ def test_model_lowers_to_a_valid_network_program(built_lib):
     check(lib.pcmi_net_destroy(h))
     offs = sorted(o["w_off"] for o in prog["ops"] if o["type"] == 0)
     assert len(set(offs)) == n_conv and offs[0] == 0
+
+
+def test_checkpoint_layout_interoperates_with_reference_format(built_lib, tmp_path):
+  """a checkpoint in the reference's layout ({state_dict, optimizer, scheduler, curr_iter, config},
+  pc/lib/ddp_trainer.py:113-133) whose state_dict uses the reference's parameter names (restated by the oracle
+  model: '<conv>.kernel' [K, Cin, Cout], '<bn>.bn.weight', 'final.bias') loads into the device model key for
+  key, strict -- no CPU compute involved, only module construction."""
+  from oracle import model_ref as mr
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_trainer import load_state
+  from pointcontrast_amd.model import load_model
+  cfg = get_config([])
+  for name in ("Res16UNet14", "Res16UNet34C"):
+    ref = mr.MODELS[name](3, 32)
+    dev = load_model(name)(3, 32, cfg, D=3)
+    sd_ref, sd_dev = ref.state_dict(), dev.state_dict()
+    assert list(sd_ref.keys()) == list(sd_dev.keys()), "parameter / buffer names or order differ"
+    for k in sd_ref:
+      assert tuple(sd_ref[k].shape) == tuple(sd_dev[k].shape), k
+    path = tmp_path / ("%s.pth" % name)
+    torch.save({"curr_iter": 7, "state_dict": sd_ref, "optimizer": {}, "scheduler": {}, "config": {}}, path)
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    load_state(dev, state["state_dict"])  # strict
+    assert torch.equal(dev.state_dict()["conv0p1s1.kernel"], sd_ref["conv0p1s1.kernel"])
+    # lenient loading keeps matching tensors and skips a head of another width (ddp_trainer.py:45-55 of the reference)
+    other = load_model(name)(3, 16, cfg, D=3)
+    load_state(other, state["state_dict"], lenient_weight_loading=True)
+    assert torch.equal(other.state_dict()["bn0.bn.weight"], sd_ref["bn0.bn.weight"])
