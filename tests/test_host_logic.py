@@ -157,3 +157,30 @@ def test_checkpoint_layout_interoperates_with_reference_format(built_lib, tmp_pa
     other = load_model(name)(3, 16, cfg, D=3)
     load_state(other, state["state_dict"], lenient_weight_loading=True)
     assert torch.equal(other.state_dict()["bn0.bn.weight"], sd_ref["bn0.bn.weight"])
+
+
+def test_engine_bucket_callback_mapping(built_lib):
+  """The native executor takes the reducer's buckets as ASCENDING flat offsets and reports a finished bucket by its
+  position in that list; NativeEngine._ready_args must translate back to the reducer's own bucket index (the
+  reducer numbers its buckets from the END of the flat buffer, the order backward finishes them)."""
+  from pointcontrast_amd.engine import NativeEngine
+
+  class StubReducer:
+    active = True
+    buckets = [(700, 1000, None), (300, 700, None), (0, 300, None)]  # (lo, hi, _), last parameters first
+
+    def __init__(self):
+      self.launched = []
+
+    def _launch(self, b):
+      self.launched.append(b)
+
+  r = StubReducer()
+  cb, lo_arr, nb = NativeEngine._ready_args(r)
+  assert nb == 3 and list(lo_arr) == [0, 300, 700]
+  for q in (2, 1, 0):  # the executor finishes the highest offsets first
+    cb(None, q)
+  assert r.launched == [0, 1, 2]
+  r.active = False
+  cb, lo_arr, nb = NativeEngine._ready_args(r)
+  assert nb == 0 and lo_arr is None
