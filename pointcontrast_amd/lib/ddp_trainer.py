@@ -181,7 +181,8 @@ class ContrastiveLossTrainer:
 
   def _prefetch_worker(self, input_dict):
     try:
-      torch.cuda.set_device(self.cur_device)
+      if self.cur_device.type == "cuda":
+        torch.cuda.set_device(self.cur_device)  # the current device is per thread
       self._prefetched = self._prepare(input_dict)
     except BaseException as e:  # re-raised on the training thread by _next_prepared
       self._prefetch_err = e

@@ -184,3 +184,38 @@ def test_engine_bucket_callback_mapping(built_lib):
   r.active = False
   cb, lo_arr, nb = NativeEngine._ready_args(r)
   assert nb == 0 and lo_arr is None
+
+
+def test_prefetch_thread_keeps_batch_order_and_reraises(built_lib):
+  """misc.prefetch_thread: batch N+1 is prepared on a helper thread while step N is enqueued; the training thread
+  must get the batches in loader order and see the helper's exceptions (host logic only: _prepare is stubbed)."""
+  import threading
+  from pointcontrast_amd.lib import ddp_trainer
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.timer import Timer
+  tr = object.__new__(ddp_trainer.PointNCELossTrainer)
+  tr.config = get_config([])
+  tr.cur_device = torch.device("cpu")
+  tr._prefetch_thread, tr._prefetch_err, tr._prefetched = None, None, None
+  seen_threads = []
+
+  def fake_prepare(input_dict, draws=None):
+    seen_threads.append(threading.current_thread().name)
+    if input_dict == "bad":
+      raise ValueError("boom")
+    return {"input": input_dict}
+
+  tr._prepare = fake_prepare
+  it = iter(["a", "b", "c", "bad", "never"])
+  got = []
+  for _ in range(3):
+    prep, _ = tr._next_prepared(it, Timer(), None)
+    tr._prefetch_start(it, None)
+    got.append(prep["input"])
+  assert got == ["a", "b", "c"]
+  assert seen_threads[0] == threading.current_thread().name and all(n != seen_threads[0] for n in seen_threads[1:])
+  with pytest.raises(ValueError, match="boom"):
+    tr._next_prepared(it, Timer(), None)  # the helper failed on "bad"
+  # fixed draws (parity tests) bypass the helper thread entirely
+  tr._prefetch_start(it, {"uniform": None})
+  assert tr._prefetch_thread is None
