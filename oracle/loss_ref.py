@@ -40,11 +40,13 @@ def hash_pairs(a, b, M):
 
 
 def hardest_contrastive_loss(F0, F1, positive_pairs, sel0, sel1, pos_sel, pos_thresh=0.1,
-                             neg_thresh=1.4):
+                             neg_thresh=1.4, forced=None):
   """pc/lib/ddp_trainer.py:186-238.  sel0/sel1: hard-negative candidate rows
   (np.random.choice at :199-200); pos_sel: sampled positive-pair indices (:203)
   or None when P <= num_pos.  Returns (pos_loss, neg_loss, aux) where aux holds
-  the mined indices and masks for integer parity checks."""
+  the mined indices and masks for integer parity checks.
+  forced = (D01ind, D10ind): use these hard negatives instead of torch's arg-min (tie-aware comparisons: at an fp32
+  tie two correct implementations may mine different rows; the caller verifies that the forced rows ARE minima)."""
   pp = np.asarray(positive_pairs, dtype=np.int64)
   N0, N1 = len(F0), len(F1)
   hash_seed = max(N0, N1)
@@ -58,8 +60,13 @@ def hardest_contrastive_loss(F0, F1, positive_pairs, sel0, sel1, pos_sel, pos_th
     D2 = torch.sum((A.unsqueeze(1) - B.unsqueeze(0)).pow(2), 2)
     return torch.sqrt(D2 + 1e-7)
 
-  D01min, D01ind = pdist(posF0, subF1).min(1)
-  D10min, D10ind = pdist(posF1, subF0).min(1)
+  if forced is None:
+    D01min, D01ind = pdist(posF0, subF1).min(1)
+    D10min, D10ind = pdist(posF1, subF0).min(1)
+  else:
+    D01ind, D10ind = (torch.from_numpy(np.asarray(f).astype(np.int64)) for f in forced)
+    D01min = torch.sqrt((posF0 - subF1[D01ind]).pow(2).sum(1) + 1e-7)
+    D10min = torch.sqrt((posF1 - subF0[D10ind]).pow(2).sum(1) + 1e-7)
   pos_keys = hash_pairs(pp[:, 0], pp[:, 1], hash_seed)
   n01 = np.asarray(sel1)[D01ind.numpy()]
   n10 = np.asarray(sel0)[D10ind.numpy()]

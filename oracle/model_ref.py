@@ -65,8 +65,47 @@ class BatchNormRef(nn.Module):
     return sr.SparseTensorRef(self.bn(x.F), coords_key=x.coords_key, coords_manager=x.coords_man)
 
 
+_RELU_IMPL = [torch.relu]  # every ReLU of the oracle goes through this slot (see relu_masks)
+
+
+def relu_features(f):
+  return _RELU_IMPL[0](f)
+
+
+class relu_masks:
+  """Context manager for deterministic gradient comparisons.  An activation that lies within fp32 round-off of
+  zero gets opposite ReLU masks in two implementations and then moves whole gradient tensors by percents -- a
+  property of ReLU, not an error of either side.  ``relu_masks(record=lst)`` appends the mask (x > 0) of every
+  ReLU call, in call order, to ``lst``; ``relu_masks(apply=lst)`` replaces ReLU by ``x * mask`` with the recorded
+  masks, so that two runs (fp64 / fp32 oracle, device) differentiate exactly the same piecewise-linear function."""
+
+  def __init__(self, record=None, apply=None):
+    assert (record is None) != (apply is None)
+    self.record, self.apply, self.pos = record, apply, 0
+
+  def _fn(self, f):
+    if self.record is not None:
+      self.record.append((f > 0).clone())
+      return torch.relu(f)
+    m = self.apply[self.pos]
+    self.pos += 1
+    assert m.shape == f.shape, "ReLU call %d: mask %s vs activation %s" % (self.pos - 1, tuple(m.shape), tuple(f.shape))
+    return f * m.to(f.dtype)
+
+  def __enter__(self):
+    self._old = _RELU_IMPL[0]
+    _RELU_IMPL[0] = self._fn
+    return self
+
+  def __exit__(self, *exc):
+    _RELU_IMPL[0] = self._old
+    if self.apply is not None and exc[0] is None:
+      assert self.pos == len(self.apply), "%d ReLU calls, %d masks" % (self.pos, len(self.apply))
+    return False
+
+
 def _relu(x):
-  return sr.SparseTensorRef(torch.relu(x.F), coords_key=x.coords_key, coords_manager=x.coords_man)
+  return sr.SparseTensorRef(relu_features(x.F), coords_key=x.coords_key, coords_manager=x.coords_man)
 
 
 class BasicBlockRef(nn.Module):
@@ -85,7 +124,7 @@ class BasicBlockRef(nn.Module):
     out = _relu(self.norm1(self.conv1(x)))
     out = self.norm2(self.conv2(out))
     res = x if self.downsample is None else self.downsample(x)
-    return sr.SparseTensorRef(torch.relu(out.F + res.F), coords_key=out.coords_key,
+    return sr.SparseTensorRef(relu_features(out.F + res.F), coords_key=out.coords_key,
                               coords_manager=out.coords_man)
 
 

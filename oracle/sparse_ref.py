@@ -199,6 +199,12 @@ class SparseTensorRef:
   def C(self):
     return self.coords_man.coords[self.coords_key]
 
+  def __add__(self, other):  # `out += residual`, pc/model/modules/resnet_block.py:57
+    assert other.coords_key == self.coords_key and other.coords_man is self.coords_man
+    return SparseTensorRef(self.F + other.F, coords_key=self.coords_key, coords_manager=self.coords_man)
+
+  __iadd__ = __add__
+
   @property
   def tensor_stride(self):
     return self.coords_man.tensor_stride[self.coords_key]

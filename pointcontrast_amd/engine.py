@@ -23,6 +23,8 @@ class _Tracer:
   def __init__(self, offset_of):
     self.offset_of = offset_of  # id(parameter) -> offset in the flat buffer
     self.tensors, self.ops, self.bn_modules = [], [], []
+    self.consumed = set()  # tensor ids some op already reads: such a tensor can no longer absorb an add / ReLU
+    self.bn_op = {}        # tensor id -> the (still open) BN op dict that produced it
 
   def new(self, channels, level):
     self.tensors.append(dict(level=level, channels=channels, parent=-1, col_off=0))
@@ -31,8 +33,14 @@ class _Tracer:
   def _off(self, p):
     return self.offset_of[id(p)]
 
+  def _use(self, *ts):
+    for t in ts:
+      if t is not None:
+        self.consumed.add(t.id)
+
   def conv(self, mod, x):
     assert x.channels == mod.in_channels, "conv input width %d != %d" % (x.channels, mod.in_channels)
+    self._use(x)
     if mod.kernel_volume == 1:
       level = x.level
     elif mod.transpose:
@@ -48,15 +56,47 @@ class _Tracer:
 
   def bn(self, mod, x, residual, relu):
     bn = mod.bn
+    self._use(x, residual)
     out = self.new(x.channels, x.level)
     self.ops.append(dict(type=OP_BN, in_=x.id, in2=residual.id if residual is not None else -1, out=out.id,
                          cin=x.channels, cout=x.channels, relu=int(bool(relu)), w_off=self._off(bn.weight),
                          b_off=self._off(bn.bias), running_mean=bn.running_mean.data_ptr(),
                          running_var=bn.running_var.data_ptr(), momentum=float(bn.momentum), eps=float(bn.eps)))
     self.bn_modules.append(mod)
+    self.bn_op[out.id] = self.ops[-1]
     return out
 
+  # -- the reference's unfused spelling (pc/model/modules/resnet_block.py:44-60): folded into the producing BN ----
+  def _open_bn(self, x, what):
+    op = self.bn_op.get(x.id)
+    if op is None or x.id in self.consumed or op["relu"]:
+      raise NotImplementedError("%s of a tensor that is not the fresh, unconsumed output of a BatchNorm cannot be "
+                                "lowered to the native engine (its ops are conv, BN(+residual)(+ReLU), L2-norm)" % what)
+    return op
+
+  def add(self, a, b):
+    """``out += residual``: the residual becomes the second input of the BatchNorm that produced ``out``.  The BN op
+    moves to the end of the program (nothing consumed its output yet), i.e. behind the residual's producer."""
+    try:
+      op, res = self._open_bn(a, "an add"), b
+    except NotImplementedError:
+      op, res = self._open_bn(b, "an add"), a
+    if op["in2"] >= 0:
+      raise NotImplementedError("a second add into the same BatchNorm output cannot be lowered")
+    assert res.channels == op["cout"] and res.level == self.tensors[op["out"]]["level"], "add: shapes differ"
+    self._use(res)
+    op["in2"] = res.id
+    self.ops.remove(op)
+    self.ops.append(op)
+    return ME.SymTensor(self, op["out"], op["cout"], res.level)
+
+  def relu(self, x):
+    op = self._open_bn(x, "a ReLU")
+    op["relu"] = 1
+    return ME.SymTensor(self, x.id, x.channels, x.level)
+
   def cat(self, ts):
+    self._use(*ts)
     level = ts[0].level
     parent = self.new(sum(t.channels for t in ts), level)
     col = 0
@@ -68,6 +108,7 @@ class _Tracer:
     return parent
 
   def l2norm(self, x):
+    self._use(x)
     out = self.new(x.channels, x.level)
     self.ops.append(dict(type=OP_L2NORM, in_=x.id, in2=-1, out=out.id, cin=x.channels, cout=x.channels))
     return out
@@ -90,6 +131,32 @@ def lower_model(model, flat, in_channels=3):
                  o.get("momentum", 0.0), o.get("eps", 0.0))
   return dict(T=T, O=O, tensors=tr.tensors, ops=tr.ops, input=x.id, output=y.id, out_channels=y.channels,
               n_down=max(t["level"] for t in tr.tensors), bn_modules=tr.bn_modules)
+
+
+def canonical_program(prog):
+  """The program with tensors renumbered in order of first use (input first), as plain tuples: two models lower to
+  the same network iff these are equal (tests: the reference's unmodified model source vs. this package's)."""
+  tensors, ops = prog["tensors"], prog["ops"]
+  order = {}
+
+  def num(t):
+    if t < 0:
+      return -1
+    if t not in order:
+      order[t] = len(order)
+      if tensors[t]["parent"] >= 0:
+        num(tensors[t]["parent"])
+    return order[t]
+
+  num(prog["input"])
+  keys = ("type", "cin", "cout", "kernel_size", "stride", "region", "transpose", "relu", "has_bias", "w_off", "b_off",
+          "momentum", "eps")
+  cops = []
+  for o in ops:
+    cops.append((num(o["in_"]), num(o["in2"]), num(o["out"])) + tuple(o.get(k, 0) for k in keys))
+  inv = sorted(order, key=order.get)
+  ctens = [(tensors[t]["level"], tensors[t]["channels"], num(tensors[t]["parent"]), tensors[t]["col_off"]) for t in inv]
+  return dict(tensors=ctens, ops=cops, input=order[prog["input"]], output=order[prog["output"]])
 
 
 def create_net(prog, n_passes=2):

@@ -12,6 +12,7 @@ path and raises NotImplementedError.
 """
 import ctypes as C
 import math
+import sys
 import types
 from enum import Enum
 
@@ -202,7 +203,11 @@ class CoordsManager:
 
 class SymTensor:
   """Stand-in for a SparseTensor while a model is being lowered to a libpcmi network program
-  (pointcontrast_amd/engine.py): the modules record ops on `tracer` instead of launching kernels."""
+  (pointcontrast_amd/engine.py): the modules record ops on `tracer` instead of launching kernels.
+  Model code written in the reference's unfused style -- ``relu(bn(x))``, ``out += residual; relu(out)``,
+  ``SparseTensor(out.F / torch.norm(out.F, p=2, dim=1, keepdim=True), ...)`` (pc/model/modules/resnet_block.py:44-60,
+  pc/model/res16unet.py:262-266) -- lowers to the same fused ops: the tracer folds the add / ReLU into the
+  BatchNorm that produced the tensor."""
 
   def __init__(self, tracer, tid, channels, level):
     self.tracer, self.id, self.channels, self.level = tracer, tid, channels, level
@@ -210,12 +215,34 @@ class SymTensor:
 
   @property
   def F(self):
-    raise NotImplementedError("a model that touches .F directly cannot be lowered to the native engine")
+    return SymFeatures(self, "raw")
 
   def __add__(self, other):
-    raise NotImplementedError("use the fused MinkowskiBatchNorm(x, residual=...) form in models meant for the engine")
+    return self.tracer.add(self, other)
 
   __iadd__ = __add__
+
+
+class SymFeatures:
+  """`.F` of a SymTensor.  The only arithmetic a lowered model may do on it is the reference's L2 row
+  normalisation ``F / torch.norm(F, p=2, dim=1, keepdim=True)``; anything else cannot be expressed as a libpcmi op."""
+
+  def __init__(self, sym, kind):
+    self.sym, self.kind = sym, kind
+
+  @classmethod
+  def __torch_function__(cls, func, types, args=(), kwargs=None):
+    kwargs = kwargs or {}
+    if func is torch.norm and len(args) == 1 and isinstance(args[0], SymFeatures) and args[0].kind == "raw" and \
+        kwargs.get("p", 2) == 2 and kwargs.get("dim") == 1 and kwargs.get("keepdim") is True:
+      return SymFeatures(args[0].sym, "rownorm")
+    raise NotImplementedError("%s on the features of a symbolic tensor cannot be lowered to the native engine" %
+                              getattr(func, "__name__", func))
+
+  def __truediv__(self, other):
+    if self.kind == "raw" and isinstance(other, SymFeatures) and other.kind == "rownorm" and other.sym is self.sym:
+      return SymFeatures(self.sym, "l2normalized")
+    raise NotImplementedError("only F / torch.norm(F, p=2, dim=1, keepdim=True) can be lowered")
 
 
 class SparseTensor:
@@ -224,6 +251,13 @@ class SparseTensor:
 
   As in the reference a tensor may be built from CPU tensors and moved with ``.to(device)``;
   the coordinate hash is created on the device at that point."""
+
+  def __new__(cls, feats=None, *args, **kwargs):
+    if isinstance(feats, SymFeatures):  # model being lowered: SparseTensor(F / ||F||, coords_key=..., coords_manager=...)
+      if feats.kind != "l2normalized":
+        raise NotImplementedError("a SparseTensor built from raw symbolic features cannot be lowered")
+      return feats.sym.tracer.l2norm(feats.sym)  # a SymTensor: __init__ is skipped
+    return super().__new__(cls)
 
   def __init__(self, feats, coords=None, coords_key=None, coords_manager=None, force_creation=False,
                allow_duplicate_coords=False, tensor_stride=1):
@@ -429,7 +463,7 @@ class MinkowskiReLU(nn.Module):
 
   def forward(self, x):
     if isinstance(x, SymTensor):
-      raise NotImplementedError("standalone ReLU is not lowered; use MinkowskiBatchNorm(x, relu=True)")
+      return x.tracer.relu(x)
     return SparseTensor(PF.ReLUFunction.apply(x.F), coords_key=x.coords_key, coords_manager=x.coords_man)
 
 
@@ -492,5 +526,20 @@ MinkowskiAvgPooling = _not_on_hot_path("MinkowskiAvgPooling")
 MinkowskiAvgUnpooling = _not_on_hot_path("MinkowskiAvgUnpooling")
 MinkowskiSumPooling = _not_on_hot_path("MinkowskiSumPooling")
 
-MinkowskiOps = types.SimpleNamespace(cat=cat)
+MinkowskiOps = types.ModuleType("MinkowskiEngine.MinkowskiOps")
+MinkowskiOps.cat = cat
 utils = types.SimpleNamespace(sparse_quantize=_sparse_quantize)
+
+
+def install():
+  """Registers this module as ``MinkowskiEngine`` (and its ``MinkowskiOps`` submodule), so that code written
+  against ME 0.4.3 -- ``import MinkowskiEngine as ME``, ``from MinkowskiEngine import SparseTensor``,
+  ``import MinkowskiEngine.MinkowskiOps as me`` (pc/model/res16unet.py:10-12, pc/lib/ddp_trainer.py:26) -- runs on
+  libpcmi without touching its import lines.  Call before importing such code.  Refuses to shadow a real ME."""
+  me = sys.modules[__name__]
+  cur = sys.modules.get("MinkowskiEngine")
+  if cur is not None and cur is not me and hasattr(cur, "MinkowskiEngineBackend"):
+    raise RuntimeError("a real MinkowskiEngine is already imported")
+  sys.modules["MinkowskiEngine"] = me
+  sys.modules["MinkowskiEngine.MinkowskiOps"] = MinkowskiOps
+  return me

@@ -19,12 +19,13 @@ class BasicBlockBase(nn.Module):
 
   def forward(self, x):
     out = self.norm1(self.conv1(x), relu=True)
+    out = self.conv2(out)  # before the shortcut, the order of the reference's forward (:46-55)
     if self.downsample is None:
       shortcut = x
     else:  # nn.Sequential(1x1 conv, BN) built by ResNetBase._make_layer
       shortcut = self.downsample[1](self.downsample[0](x))
     # relu(norm2(conv2(out)) + shortcut) in one pass over the activation
-    return self.norm2(self.conv2(out), residual=shortcut, relu=True)
+    return self.norm2(out, residual=shortcut, relu=True)
 
 
 class BasicBlock(BasicBlockBase):
