@@ -177,7 +177,8 @@ def cpu_baseline(batch_size_sample=1):
   nq = len(np.unique(pp[:, 0]))
   rng = np.random.RandomState(0)
   times = []
-  for it in range(2):
+  n_timed = int(os.environ.get("PCMI_CPU_BASELINE_ITERS", "3"))  # >= 3 timed iterations, same inputs
+  for it in range(1 + n_timed):
     t0 = time.perf_counter()
     opt.zero_grad()
     F0 = model(sr.SparseTensorRef(b["sinput0_F"], coords=b["sinput0_C"].numpy())).F
@@ -188,13 +189,16 @@ def cpu_baseline(batch_size_sample=1):
     loss.backward()
     opt.step()
     times.append(time.perf_counter() - t0)
-  return {"value": round(batch_size_sample / times[-1], 4), "unit": "scene-pairs/sec", "cores": torch.get_num_threads(),
-          "kind": "port",
-          "sample": "%d pair(s) (N0=%d, N1=%d voxels), full oracle iteration (2 fwd + NCE + bwd + SGD), 1 untimed + 1 timed"
-                    % (batch_size_sample, b["sinput0_C"].shape[0], b["sinput1_C"].shape[0])}
+  timed = times[1:]
+  return {"value": round(batch_size_sample * len(timed) / sum(timed), 4), "unit": "scene-pairs/sec",
+          "cores": torch.get_num_threads(), "kind": "port",
+          "sample": "%d pair(s) (N0=%d, N1=%d voxels), full oracle iteration (2 fwd + NCE + bwd + SGD), 1 untimed + %d "
+                    "timed (%s s each), time.perf_counter"
+                    % (batch_size_sample, b["sinput0_C"].shape[0], b["sinput1_C"].shape[0], len(timed),
+                       "/".join("%.1f" % t for t in timed))}
 
 
-def run_cpu_baseline_bounded(limit_s=240):
+def run_cpu_baseline_bounded(limit_s=300):
   """Runs cpu_baseline() in a child process so that a slow host cannot stall the bench line."""
   import subprocess
   code = "import json, bench; print('CPUBASE' + json.dumps(bench.cpu_baseline(1)))"
@@ -208,6 +212,17 @@ def run_cpu_baseline_bounded(limit_s=240):
   except subprocess.TimeoutExpired:
     return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "kind": "port",
             "sample": "1 pair did not finish within %d s on this host" % limit_s}
+
+
+def workload_label(args):
+  """Which BASELINE.json config the run has the shape of (by voxel size / loss / batch), else 'custom'."""
+  if args.model != "Res16UNet34C" or args.batch != 4:
+    return "custom (not a BASELINE config)"
+  if abs(args.voxel - 0.025) < 1e-9:
+    return "BASELINE configs[1]" if args.loss == "nce" else "BASELINE configs[2]"
+  if abs(args.voxel - 0.01) < 1e-9 and args.loss == "nce":
+    return "BASELINE configs[4] shape (1 cm voxels) on %d GPU(s)" % args.gpus
+  return "custom (not a BASELINE config)"
 
 
 def log(msg):
@@ -251,7 +266,7 @@ def main():
   from pointcontrast_amd.lib.timer import AverageMeter, Timer
   cfg = get_config(["net.model=%s" % args.model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1",
                     "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world),
-                    "misc.engine=%s" % args.engine] + list(args.set))
+                    "misc.engine=%s" % args.engine, "misc.host_profile=True"] + list(args.set))
   batch = get_batch(seed=rank, batch_size=args.batch, voxel_size=args.voxel)
   loader = FixedBatchLoader([batch], batch_size=args.batch)
   torch.manual_seed(0)
@@ -292,15 +307,16 @@ def main():
       torch.cuda.synchronize()
     flops, byts, rows = conv_work(trainer.model)  # cloud 1
     out = {
-        "metric": "scene-pairs/sec, ScanNet 2.5cm Res16UNet34C PointInfoNCE" if args.loss == "nce" else
-                  "scene-pairs/sec, ScanNet 2.5cm Res16UNet34C HardestContrastive",
+        "metric": "scene-pairs/sec, ScanNet %s Res16UNet34C %s" % (
+            "2.5cm" if abs(args.voxel - 0.025) < 1e-9 else "%gcm" % (args.voxel * 100),
+            "PointInfoNCE" if args.loss == "nce" else "HardestContrastive"),
         "value": round(args.batch * world * args.steps / elapsed, 3), "unit": "scene-pairs/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%d]: %s, %s loss, voxel %.3g m, %d pairs/GPU, %d+%d active voxels per "
+        "config": {"workload": "%s: %s, %s loss, voxel %.3g m, %d pairs/GPU, %d+%d active voxels per "
                                "forward pair on rank 0, npos 4096, T 0.4, SGD(lr 0.1, mom 0.8, wd 1e-4)"
-                               % (1 if args.loss == "nce" else 2, args.model, args.loss, args.voxel, args.batch, n0, n1),
+                               % (workload_label(args), args.model, args.loss, args.voxel, args.batch, n0, n1),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine, "final_loss": round(loss_val, 5),
                    "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),

@@ -81,8 +81,6 @@ struct OpPlan {
   int acc_res = 0;  // gradient w.r.t. `in2` (BN residual) accumulates
 };
 
-struct BnGradAdd;
-
 struct PassState {
   PassState() = default;
   PassState(const PassState&) = delete;  // owns device / pinned memory and events
@@ -98,22 +96,12 @@ struct PassState {
   DevBuf grad;
   std::vector<size_t> grad_off;
   DevBuf small;  // dgamma / dbeta scratch
-  // pass run as the DEFERRED half of pcmi_net_backward_pair: BN parameter-gradient slots, the table that adds
-  // them to the flat gradients, and how far the pass got at every bucket boundary (event + table size)
-  DevBuf bn_slots;
-  BnGradAdd* gadd_host = nullptr;  // pinned
-  BnGradAdd* gadd_dev = nullptr;
-  int gadd_cap = 0, gadd_n = 0;
-  hipEvent_t gadd_copied = nullptr;
-  std::vector<int> gadd_mark;
+  // pass run as the DEFERRED half of pcmi_net_backward_pair: how far it got at every bucket boundary
   std::vector<hipEvent_t> bucket_ev;
   ~PassState() {
     if (upd_host) (void)hipHostFree(upd_host);
     if (upd_dev) (void)hipFree(upd_dev);
     if (upd_copied) (void)hipEventDestroy(upd_copied);
-    if (gadd_host) (void)hipHostFree(gadd_host);
-    if (gadd_dev) (void)hipFree(gadd_dev);
-    if (gadd_copied) (void)hipEventDestroy(gadd_copied);
     for (hipEvent_t e : bucket_ev) (void)hipEventDestroy(e);
   }
   std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
@@ -138,17 +126,23 @@ struct pcmi_net {
   int input_tensor = -1, output_tensor = -1, n_levels = 0;
   std::vector<pcmi::PassState> passes;
   // backward: the weight gradients (off the critical path: nothing downstream reads them) run on a side stream
-  // next to the bwd-data -> BN-bwd chain; their slabs need a workspace of their own
-  hipStream_t side = nullptr;
+  // next to the bwd-data -> BN-bwd chain, with a workspace of their own.  pcmi_net_backward_pair runs the two passes
+  // of an iteration concurrently: each has its own chain stream, weight-gradient stream and workspace, and pass 1
+  // writes its parameter gradients to `grads_peer` (added to the caller's buffer bucket by bucket by pass 0).
+  hipStream_t side[2] = {nullptr, nullptr};
   hipStream_t chain1 = nullptr;  // chain stream of pass 1 in pcmi_net_backward_pair
-  hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_fork = nullptr;
-  pcmi::DevBuf ws_side;
+  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_fork = nullptr;
+  pcmi::DevBuf ws_side[2];
+  pcmi::DevBuf grads_peer;
+  int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
   ~pcmi_net() {
     (void)hipDeviceSynchronize();
-    if (side) (void)hipStreamDestroy(side);
+    for (int i = 0; i < 2; ++i) {
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+      if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
+      if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
+    }
     if (chain1) (void)hipStreamDestroy(chain1);
-    if (ev_main) (void)hipEventDestroy(ev_main);
-    if (ev_side) (void)hipEventDestroy(ev_side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
   }
 };
@@ -199,11 +193,13 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
 
 // ---- backward -----------------------------------------------------------------------------------------
 // One pass's backward is a chain (bwd-data -> BN-bwd -> ...) on a "chain" stream plus the weight gradients,
-// which nothing downstream reads, on the shared side stream.  pcmi_net_backward_pair runs the two passes of an
-// iteration next to each other: pass 1 (DEFERRED) on the executor's second chain stream, pass 0 (PRIMARY) on
-// the caller's; both enqueue their weight gradients on the ONE side stream (pass 1 first, so the accumulation
-// order into `grads` is that of two sequential backwards).  The BN parameter gradients of the DEFERRED pass go
-// to per-op slots and are added to `grads` by the PRIMARY pass before a bucket is declared final.
+// which nothing downstream reads, on a weight-gradient stream.  pcmi_net_backward_pair runs the two passes of an
+// iteration next to each other: pass 1 (DEFERRED) on the executor's second chain stream + second weight-gradient
+// stream, writing its parameter gradients (each parameter belongs to exactly one op, so they are plain stores) to
+// the executor's peer buffer; pass 0 (PRIMARY) on the caller's stream, accumulating into the caller's `grads` as a
+// solo pass does.  When PRIMARY reaches a bucket boundary it waits for DEFERRED to have passed the same boundary,
+// adds the peer buffer's slice and only then declares the bucket final.  (0 + g0) + g1 == (0 + g1) + g0 bit for bit,
+// so the result equals two sequential backwards into a zeroed buffer.
 struct BackwardJob {
   enum Role { SOLO, DEFERRED, PRIMARY };
   int pass = 0;
@@ -213,32 +209,31 @@ struct BackwardJob {
   Role role = SOLO;
 };
 
-struct BnGradAdd {  // grads[dst_gamma + ch] += src[ch]; grads[dst_beta + ch] += src[c + ch]
-  float* dst_gamma;
-  float* dst_beta;
-  const float* src;
-  int c;
-};
-
-__global__ __launch_bounds__(256) void bn_grad_add_kernel(const BnGradAdd* __restrict__ tab) {
-  const BnGradAdd e = tab[blockIdx.x];
-  for (int ch = threadIdx.x; ch < e.c; ch += 256) {
-    e.dst_gamma[ch] += e.src[ch];
-    e.dst_beta[ch] += e.src[e.c + ch];
+__global__ __launch_bounds__(256) void grads_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 d = reinterpret_cast<float4*>(dst)[i];
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    d.x += v.x;
+    d.y += v.y;
+    d.z += v.z;
+    d.w += v.w;
+    reinterpret_cast<float4*>(dst)[i] = d;
   }
 }
 
 static int ensure_streams(pcmi_net& n) {
-  if (n.side) return PCMI_OK;
+  if (n.side[0]) return PCMI_OK;
   // the weight gradients are off the critical path: lowest priority, so that the chain's kernels are dispatched
   // first and the weight-gradient workgroups fill what they leave idle (PCMI_WGRAD_PRIORITY=0: same priority)
   int least = 0, greatest = 0;
   PCMI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
   const char* pe = getenv("PCMI_WGRAD_PRIORITY");
   const int prio = (pe && pe[0] == '0') ? 0 : least;
-  PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side, hipStreamNonBlocking, prio));
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main, hipEventDisableTiming));
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, prio));
+    PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
+    PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
+  }
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
   return PCMI_OK;
 }
@@ -268,77 +263,51 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
   float* scratch_g = (float*)ps.small.p;
   const bool deferred = job.role == BackwardJob::DEFERRED, primary = job.role == BackwardJob::PRIMARY;
   PassState* peer = primary ? &n.passes[1] : nullptr;
-  // ---- deferred BN parameter gradients: slots + table ------------------------------------------------
-  int n_bn = 0;
-  size_t slot_bytes = 0;
-  if (deferred) {
-    for (int i = 0; i < n_ops; ++i)
-      if (n.ops[i].type == PCMI_OP_BN) {
-        ++n_bn;
-        slot_bytes += align_up((size_t)2 * n.ops[i].cout * sizeof(float), 256);
-      }
-    rc = ps.bn_slots.reserve(slot_bytes, st);
-    if (rc) return rc;
-    if (n_bn > ps.gadd_cap) {
-      PCMI_HIP_CHECK(hipDeviceSynchronize());
-      if (ps.gadd_host) PCMI_HIP_CHECK(hipHostFree(ps.gadd_host));
-      if (ps.gadd_dev) PCMI_HIP_CHECK(hipFree(ps.gadd_dev));
-      ps.gadd_host = nullptr;
-      ps.gadd_dev = nullptr;
-      PCMI_HIP_CHECK(hipHostMalloc((void**)&ps.gadd_host, sizeof(BnGradAdd) * n_bn, hipHostMallocDefault));
-      PCMI_HIP_CHECK(hipMalloc((void**)&ps.gadd_dev, sizeof(BnGradAdd) * n_bn));
-      ps.gadd_cap = n_bn;
-    }
-    if (!ps.gadd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.gadd_copied, hipEventDisableTiming));
-    PCMI_HIP_CHECK(hipEventSynchronize(ps.gadd_copied));  // the previous table has left the pinned buffer
-    ps.gadd_n = 0;
-    ps.gadd_mark.assign(n_buckets + 1, 0);
+  // where this pass's parameter gradients go: DEFERRED stores into the peer buffer, the others accumulate
+  float* gdst = deferred ? (float*)n.grads_peer.p : grads;
+  const int gacc = deferred ? 0 : 1;
+  if (deferred)
     while ((int)ps.bucket_ev.size() < n_buckets + 1) {
       hipEvent_t e;
       PCMI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       ps.bucket_ev.push_back(e);
     }
-  }
-  size_t slot_off = 0;
-  int gadd_applied = 0;  // PRIMARY: entries of the peer's table already added to grads
   // ---- weight-gradient stream ------------------------------------------------------------------------
   static const bool side_enabled = [] {
     const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
     return !(e && e[0] == '0');
   }();
+  const int sidx = deferred ? 1 : 0;
   hipStream_t wst = st;
   DevBuf* wws = &ps.ws;
   if (side_enabled || job.role != BackwardJob::SOLO) {
     rc = ensure_streams(n);
     if (rc) return rc;
-    rc = n.ws_side.reserve(ps.ws.cap, n.side);
+    rc = n.ws_side[sidx].reserve(ps.ws.cap, n.side[sidx]);
     if (rc) return rc;
-    wst = n.side;
-    wws = &n.ws_side;
+    wst = n.side[sidx];
+    wws = &n.ws_side[sidx];
   }
   bool side_pending = false;
   auto join_side = [&]() -> int {  // `st` continues only after the weight gradients enqueued so far
     if (!side_pending) return PCMI_OK;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_side, n.side));
-    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side, 0));
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_side[sidx], wst));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[sidx], 0));
     side_pending = false;
     return PCMI_OK;
   };
-  if (primary && peer->gadd_n > 0) {  // the peer's table (built while its backward was enqueued) -> device
-    PCMI_HIP_CHECK(hipMemcpyAsync(peer->gadd_dev, peer->gadd_host, sizeof(BnGradAdd) * peer->gadd_n, hipMemcpyHostToDevice, st));
-    PCMI_HIP_CHECK(hipEventRecord(peer->gadd_copied, st));
-  }
-  // everything the DEFERRED peer contributes to bucket q (q == n_buckets: to the whole backward) is in `grads`
-  auto absorb_peer = [&](int q) -> int {
-    side_pending = true;  // the peer's weight gradients sit on the side stream ahead of ours
+  auto bucket_hi = [&](int q) { return q + 1 < n_buckets ? bucket_lo_host[q + 1] : n.param_extent; };
+  // everything the DEFERRED peer contributes to [lo, hi) is added to `grads` (q: the peer's boundary event)
+  auto absorb_peer = [&](int q, int64_t lo, int64_t hi) -> int {
     int r = join_side();
     if (r) return r;
     PCMI_HIP_CHECK(hipStreamWaitEvent(st, peer->bucket_ev[q], 0));
-    const int upto = peer->gadd_mark[q];
-    if (upto > gadd_applied) {
-      bn_grad_add_kernel<<<upto - gadd_applied, 256, 0, st>>>(peer->gadd_dev + gadd_applied);
+    lo = lo / 4 * 4;
+    const int64_t n4 = (std::min(hi, n.param_extent) - lo + 3) / 4;
+    if (n4 > 0) {
+      const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n4, 256), 2048);
+      grads_add_kernel<<<blocks, 256, 0, st>>>(grads + lo, (const float*)n.grads_peer.p + lo, n4);
       PCMI_LAUNCH_CHECK();
-      gadd_applied = upto;
     }
     return PCMI_OK;
   };
@@ -365,12 +334,12 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
     if (op.type == PCMI_OP_CONV) {
       const pcmi_kmap_t* map = ps.has_map[i] ? &ps.maps[i] : nullptr;
       if (wst != st) {  // dy is complete at this point of `st` (all its consumers were differentiated before)
-        PCMI_HIP_CHECK(hipEventRecord(n.ev_main, st));
-        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main, 0));
+        PCMI_HIP_CHECK(hipEventRecord(n.ev_main[sidx], st));
+        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sidx], 0));
         side_pending = true;
       }
       rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
-                                  grads + op.w_off, op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
+                                  gdst + op.w_off, op.has_bias ? gdst + op.b_off : nullptr, gacc, wws->p, wws->cap, wst);
       if (rc) return rc;
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, ps, op.in, d_out, d_ld);
@@ -386,11 +355,9 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
       float* dbeta = scratch_g + op.cout;
       float* acc_g = grads + op.w_off;
       float* acc_b = grads + op.b_off;
-      if (deferred) {
-        dgamma = (float*)(ps.bn_slots.p + slot_off);
-        dbeta = dgamma + op.cout;
-        slot_off += align_up((size_t)2 * op.cout * sizeof(float), 256);
-        ps.gadd_host[ps.gadd_n++] = {acc_g, acc_b, dgamma, op.cout};
+      if (deferred) {  // the sums ARE this pass's parameter gradients: stored straight into the peer buffer
+        dgamma = gdst + op.w_off;
+        dbeta = gdst + op.b_off;
         acc_g = acc_b = nullptr;
       }
       rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats,
@@ -404,24 +371,26 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
     if (rc) return rc;
     for (int b = 0; b < n_buckets; ++b)
       if (bucket_last[b] == i) {
-        if (deferred) {  // mark how far this pass got: chain event + number of BN slots written
-          ps.gadd_mark[b] = ps.gadd_n;
-          PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[b], st));
-        } else if (ready) {
-          rc = primary ? absorb_peer(b) : join_side();
+        if (deferred) {  // everything this pass contributes to bucket b is in the peer buffer behind this event
+          rc = join_side();
           if (rc) return rc;
-          ready(ready_ctx, b);
+          PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[b], st));
+        } else {
+          rc = primary ? absorb_peer(b, bucket_lo_host[b], bucket_hi(b)) : join_side();
+          if (rc) return rc;
+          if (ready) ready(ready_ctx, b);
         }
       }
   }
+  rc = join_side();
+  if (rc) return rc;
   if (deferred) {
-    ps.gadd_mark[n_buckets] = ps.gadd_n;
     PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[n_buckets], st));
-  } else {
-    // the gradient arena / grads are reused by whatever `st` runs next
-    rc = primary ? absorb_peer(n_buckets) : join_side();
+  } else if (primary) {
+    // no buckets: the whole peer buffer at once; with buckets: only ordering (the peer is done with its arenas)
+    rc = n_buckets == 0 ? absorb_peer(0, 0, n.param_extent) : absorb_peer(n_buckets, 0, 0);
     if (rc) return rc;
-    if (primary) peer->valid = false;
+    peer->valid = false;
   }
   if (!deferred) ps.valid = false;
   return PCMI_OK;
@@ -482,6 +451,13 @@ int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_
     if (op.in < 0 || op.in >= n_tensors || op.out < 0 || op.out >= n_tensors || op.in2 >= n_tensors)
       return fail("bad tensor id in op", i);
     if (op.type == PCMI_OP_CONV) {
+      const int64_t K = (int64_t)op.kernel_size * op.kernel_size * op.kernel_size;
+      n->param_extent = std::max<int64_t>(n->param_extent, op.w_off + K * op.cin * op.cout);
+      if (op.has_bias) n->param_extent = std::max<int64_t>(n->param_extent, op.b_off + op.cout);
+    } else if (op.type == PCMI_OP_BN) {
+      n->param_extent = std::max<int64_t>(n->param_extent, std::max(op.w_off, op.b_off) + op.cout);
+    }
+    if (op.type == PCMI_OP_CONV) {
       if (n->tensors[op.in].channels != op.cin || n->tensors[op.out].channels != op.cout) return fail("conv channels", i);
       if (op.in != input_tensor && !contribute(op.in, &n->plan[i].acc_in)) return fail("mixed gradient coverage", i);
     } else if (op.type == PCMI_OP_BN) {
@@ -494,6 +470,7 @@ int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_
       return fail("unknown op type", i);
     }
   }
+  n->param_extent = (n->param_extent + 3) / 4 * 4;
   *out = n;
   return PCMI_OK;
 }
@@ -505,8 +482,8 @@ int pcmi_net_destroy(pcmi_net_t* net) {
 
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
-  size_t b = net->ws_side.cap;
-  for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap + p.bn_slots.cap;
+  size_t b = net->ws_side[0].cap + net->ws_side[1].cap + net->grads_peer.cap;
+  for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap;
   *bytes = b;
   return PCMI_OK;
 }
@@ -677,6 +654,12 @@ int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, 
   int rc = ensure_streams(n);
   if (rc) return rc;
   if (!n.chain1) PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.chain1, hipStreamNonBlocking));  // only if ever used
+  if ((size_t)n.param_extent * sizeof(float) > n.grads_peer.cap) {
+    rc = n.grads_peer.reserve((size_t)n.param_extent * sizeof(float), st);
+    if (rc) return rc;
+    // once: the gaps between parameters stay zero ever after (ops only store into parameter ranges)
+    PCMI_HIP_CHECK(hipMemsetAsync(n.grads_peer.p, 0, n.grads_peer.cap, st));
+  }
   // pass 1 on the executor's second chain stream, after whatever `st` holds now (d_out1, the zero-filled grads)
   PCMI_HIP_CHECK(hipEventRecord(n.ev_fork, st));
   PCMI_HIP_CHECK(hipStreamWaitEvent(n.chain1, n.ev_fork, 0));

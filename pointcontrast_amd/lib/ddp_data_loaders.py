@@ -2,20 +2,99 @@
 :272-309): a dict of CPU tensors
   sinput{0,1}_C int32 [N,4] (batch id FIRST), sinput{0,1}_F fp32 [N,3], correspondences int32
   [P,2] sorted by column 0 with per-item row offsets, pcd{0,1}, T_gt, len_batch.
-ScanNet itself is not available (licence + no network), so the dataset is the seeded
-synthetic generator of lib/synthetic.py pushed through the same per-item chain; a real
-ScanNetMatchPairDataset only has to yield the same item tuples."""
+Two datasets yield the same 8-tuple items (xyz0, xyz1, coords0, coords1, feats0, feats1, matches, trans):
+  * ScanNetMatchPairDataset -- the reference's (:119-270): a pair list (txt, two npz paths per line) under
+    data.dataset_root_dir / data.scannet_match_dir, each npz holding a 'pcd' array; random scale / rotation,
+    first-occurrence voxelisation, radius-1.5-voxel correspondences, Jitter;
+  * SyntheticScanNetPairDataset -- ScanNet itself is not available here (licence + no network): the seeded generator
+    of lib/synthetic.py pushed through the same per-item chain (default, used by bench.py and the tests)."""
+import logging
+import os
+import random
+
 import numpy as np
 import torch
 import torch.utils.data
+from scipy.spatial import cKDTree
 
 from . import synthetic
-from .data_sampler import DistributedInfSampler
+from . import transforms as t
+from .data_sampler import DistributedInfSampler, InfSampler
+
+
+def get_matching_indices(xyz0, xyz1, trans, search_radius, K=None):
+  """All (i, j) with |trans(xyz0[i]) - xyz1[j]| <= radius, ordered by i (pc/lib/ddp_data_loaders.py:36-49; the
+  reference walks an open3d KD-tree point by point -- here one batched cKDTree query)."""
+  src = xyz0 @ trans[:3, :3].T + trans[:3, 3]
+  nb = cKDTree(xyz1).query_ball_point(src, search_radius)
+  if K is not None:
+    nb = [x[:K] for x in nb]
+  cnt = np.fromiter((len(x) for x in nb), np.int64, len(nb))
+  ii = np.repeat(np.arange(len(nb)), cnt)
+  jj = np.concatenate([np.sort(np.asarray(x, np.int64)) for x in nb]) if cnt.sum() else np.zeros(0, np.int64)
+  return np.stack([ii, jj], 1)
+
+
+class ScanNetMatchPairDataset(torch.utils.data.Dataset):
+  """pc/lib/ddp_data_loaders.py:119-270."""
+
+  def __init__(self, phase, transform=None, random_rotation=True, random_scale=True, manual_seed=False, config=None):
+    if phase != "train":
+      raise NotImplementedError("only the train split is defined (as in the reference)")
+    self.phase, self.transform = phase, transform
+    self.voxel_size = config.data.voxel_size
+    self.matching_search_voxel_size = config.data.voxel_size * config.trainer.positive_pair_search_voxel_size_multiplier
+    self.random_scale, self.random_rotation = random_scale, random_rotation
+    self.min_scale, self.max_scale = config.trainer.min_scale, config.trainer.max_scale
+    self.rotation_range = config.trainer.rotation_range
+    self.randg = np.random.RandomState()
+    if manual_seed:
+      self.reset_seed()
+    self.root = config.data.dataset_root_dir
+    if not self.root or not config.data.scannet_match_dir:
+      raise ValueError("ScanNetMatchPairDataset needs data.dataset_root_dir and data.scannet_match_dir (the pair list)")
+    fname_txt = os.path.join(self.root, config.data.scannet_match_dir)
+    logging.info("Loading the subset %s from %s", phase, fname_txt)
+    with open(fname_txt) as f:
+      self.files = [ln.split()[:2] for ln in f if len(ln.split()) >= 2]
+
+  def reset_seed(self, seed=0):
+    self.randg.seed(seed)
+
+  def __len__(self):
+    return len(self.files)
+
+  def __getitem__(self, idx):
+    from .. import minkowski as ME
+    xyz0 = np.load(os.path.join(self.root, self.files[idx][0]))["pcd"]
+    xyz1 = np.load(os.path.join(self.root, self.files[idx][1]))["pcd"]
+    radius = self.matching_search_voxel_size
+    if self.random_scale and random.random() < 0.95:
+      scale = self.min_scale + (self.max_scale - self.min_scale) * random.random()
+      radius *= scale
+      xyz0, xyz1 = scale * xyz0, scale * xyz1
+    if self.random_rotation:
+      T0 = synthetic.sample_random_trans(xyz0, self.randg, self.rotation_range)
+      T1 = synthetic.sample_random_trans(xyz1, self.randg, self.rotation_range)
+      trans = T1 @ np.linalg.inv(T0)
+      xyz0 = xyz0 @ T0[:3, :3].T + T0[:3, 3]
+      xyz1 = xyz1 @ T1[:3, :3].T + T1[:3, 3]
+    else:
+      trans = np.identity(4)
+    xyz0 = xyz0[ME.utils.sparse_quantize(xyz0 / self.voxel_size, return_index=True)]
+    xyz1 = xyz1[ME.utils.sparse_quantize(xyz1 / self.voxel_size, return_index=True)]
+    matches = get_matching_indices(xyz0, xyz1, trans, radius)
+    feats0, feats1 = np.ones((len(xyz0), 3)), np.ones((len(xyz1), 3))
+    coords0, coords1 = np.floor(xyz0 / self.voxel_size), np.floor(xyz1 / self.voxel_size)
+    if self.transform:
+      coords0, feats0 = self.transform(coords0, feats0)
+      coords1, feats1 = self.transform(coords1, feats1)
+    return xyz0, xyz1, coords0, coords1, feats0, feats1, matches, trans
 
 
 class SyntheticScanNetPairDataset(torch.utils.data.Dataset):
 
-  def __init__(self, phase="train", config=None, num_pairs=None, crop=None):
+  def __init__(self, phase="train", config=None, num_pairs=None, crop=None, **_unused):
     self.voxel_size = config.data.voxel_size
     self.search_mult = config.trainer.positive_pair_search_voxel_size_multiplier
     self.num_pairs = num_pairs or config.data.get("num_pairs", 64)
@@ -36,18 +115,23 @@ def default_collate_pair_fn(list_data):
   return out
 
 
-ALL_DATASETS = [SyntheticScanNetPairDataset]
+ALL_DATASETS = [ScanNetMatchPairDataset, SyntheticScanNetPairDataset]
 dataset_str_mapping = {d.__name__: d for d in ALL_DATASETS}
 
 
 def make_data_loader(config, batch_size, num_threads=0):
+  if config.data.dataset not in dataset_str_mapping:
+    raise ValueError("Dataset %s does not exist in %s" % (config.data.dataset, ", ".join(dataset_str_mapping)))
   Dataset = dataset_str_mapping[config.data.dataset]
-  dset = Dataset(phase="train", config=config)
+  dset = Dataset(phase="train", transform=t.Compose([t.Jitter()]), random_scale=config.trainer.use_random_scale,
+                 random_rotation=config.trainer.use_random_rotation, config=config)
   batch_size = batch_size // config.misc.num_gpus  # per-GPU batch, pc/lib/ddp_data_loaders.py:292
-  sampler = DistributedInfSampler(dset) if config.misc.num_gpus > 1 else None
-  return torch.utils.data.DataLoader(dset, batch_size=batch_size, shuffle=False if sampler else True,
-                                     num_workers=num_threads, collate_fn=default_collate_pair_fn, pin_memory=False,
-                                     sampler=sampler, drop_last=True)
+  # The training loop calls iter() once and next() until opt.max_iter (pc/lib/ddp_trainer.py:128-140), so the loader
+  # must never run dry: infinite samplers on ANY number of GPUs (the reference's single-GPU DataLoader is finite and
+  # raises StopIteration after one epoch).
+  sampler = DistributedInfSampler(dset) if config.misc.num_gpus > 1 else InfSampler(dset, shuffle=True)
+  return torch.utils.data.DataLoader(dset, batch_size=batch_size, shuffle=False, num_workers=num_threads,
+                                     collate_fn=default_collate_pair_fn, pin_memory=False, sampler=sampler, drop_last=True)
 
 
 class FixedBatchLoader:

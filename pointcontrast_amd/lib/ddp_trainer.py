@@ -172,8 +172,13 @@ class ContrastiveLossTrainer:
         raise err
     nxt = getattr(self, "_prefetched", None)
     self._prefetched = None
-    if nxt is not None and draws is None:
-      return nxt, 0.0
+    if nxt is not None:
+      if draws is None:
+        for key in ("s0", "s1"):
+          if hasattr(nxt.get(key), "wait_upload"):
+            nxt[key].wait_upload()
+        return nxt, 0.0
+      logging.warning("injected draws: the prefetched batch is discarded and a fresh one is prepared")
     data_timer.tic()
     input_dict = next(data_loader_iter)
     data_time = data_timer.toc(average=False)
@@ -183,7 +188,8 @@ class ContrastiveLossTrainer:
     try:
       if self.cur_device.type == "cuda":
         torch.cuda.set_device(self.cur_device)  # the current device is per thread
-      self._prefetched = self._prepare(input_dict)
+      with ME.deferred_upload_sync():  # the compute stream waits when the batch is CONSUMED (_next_prepared)
+        self._prefetched = self._prepare(input_dict)
     except BaseException as e:  # re-raised on the training thread by _next_prepared
       self._prefetch_err = e
 
@@ -191,6 +197,8 @@ class ContrastiveLossTrainer:
     """misc.prefetch_thread: the next batch's uploads / coordinate planning (host-synchronous on the plan stream:
     ~10 ms of waiting per batch) run on a helper thread WHILE this step is enqueued, instead of after it.  The C
     calls release the GIL; the helper only touches its own coordinate handles and the plan stream."""
+    if getattr(self, "_last_iter", False):
+      return
     if draws is None and self.config.misc.get("prefetch", True) and self.config.misc.get("prefetch_thread", True):
       self._prefetch_err = None
       th = threading.Thread(target=self._prefetch_worker, args=(next(data_loader_iter),), daemon=True)
@@ -228,6 +236,8 @@ class ContrastiveLossTrainer:
     return {k: round(acc[k] / cnt[k], 3) for k in acc}
 
   def _prefetch(self, data_loader_iter, draws):
+    if getattr(self, "_last_iter", False):
+      return
     if draws is None and self.config.misc.get("prefetch", True) and not self.config.misc.get("prefetch_thread", True):
       self._prefetched = self._prepare(next(data_loader_iter))
 
@@ -260,12 +270,27 @@ class ContrastiveLossTrainer:
     self.optimizer.step()
     return result
 
+  def _prefetch_drain(self):
+    """Joins the batch-preparation helper and drops what it prepared (end of train(), or an exception in a step):
+    the helper must not be inside HIP / plan-stream calls while the process group and the interpreter tear down."""
+    th, self._prefetch_thread = getattr(self, "_prefetch_thread", None), None
+    if th is not None:
+      th.join()
+    self._prefetched, self._prefetch_err = None, None
+
   def train(self):
+    try:
+      self._train_loop()
+    finally:
+      self._prefetch_drain()
+
+  def _train_loop(self):
     curr_iter = self.curr_iter
     it = iter(self.data_loader)
     data_meter, data_timer, total_timer = AverageMeter(), Timer(), Timer()
     while curr_iter < self.config.opt.max_iter:
       curr_iter += 1
+      self._last_iter = curr_iter >= self.config.opt.max_iter  # nothing is prefetched past the last iteration
       epoch = curr_iter / max(len(self.data_loader), 1)
       result = self._train_iter(it, [data_meter, data_timer, total_timer])
       if curr_iter % self.lr_update_freq == 0 or curr_iter == 1:

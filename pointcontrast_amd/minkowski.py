@@ -10,9 +10,11 @@ Usage mirrors the reference: ``import pointcontrast_amd.minkowski as ME``.
 Anything else ME offers (pooling, instance norm, pruning ...) is outside the hot
 path and raises NotImplementedError.
 """
+import contextlib
 import ctypes as C
 import math
 import sys
+import threading
 import types
 from enum import Enum
 
@@ -201,6 +203,24 @@ class CoordsManager:
       check(lib.pcmi_coords_plan_unet(self._h, n_down, first_region, block_region, self._st()))
 
 
+_tls = threading.local()
+
+
+@contextlib.contextmanager
+def deferred_upload_sync():
+  """Inside this context (per thread) ``SparseTensor.to(device)`` does NOT make the current compute stream wait for
+  the upload / coordinate hash it enqueues on the plan stream; the event is left on the result as ``upload_event``
+  and the consumer waits on it when it actually uses the tensor (``wait_upload``).  Used by the trainer's helper
+  thread, which prepares the NEXT batch while the current step is still being enqueued: an immediate wait would
+  stall the compute stream in the middle of that step."""
+  old = getattr(_tls, "defer", False)
+  _tls.defer = True
+  try:
+    yield
+  finally:
+    _tls.defer = old
+
+
 class SymTensor:
   """Stand-in for a SparseTensor while a model is being lowered to a libpcmi network program
   (pointcontrast_amd/engine.py): the modules record ops on `tracer` instead of launching kernels.
@@ -292,10 +312,21 @@ class SparseTensor:
         cm = CoordsManager(c)
       ev = torch.cuda.Event()
       ev.record(plan)
-      cur.wait_event(ev)  # stream-ordered: the features are on the device before the compute stream reads them
       f.record_stream(cur)
-      return SparseTensor(f, coords_key=cm.key(0), coords_manager=cm)
+      out = SparseTensor(f, coords_key=cm.key(0), coords_manager=cm)
+      if getattr(_tls, "defer", False):
+        out.upload_event = ev  # see deferred_upload_sync
+      else:
+        cur.wait_event(ev)  # stream-ordered: the features are on the device before the compute stream reads them
+      return out
     return SparseTensor(self._F.to(device), coords_key=self.coords_key, coords_manager=self.coords_man)
+
+  def wait_upload(self):
+    """Makes the current stream wait for an upload deferred by deferred_upload_sync (no-op otherwise)."""
+    ev = getattr(self, "upload_event", None)
+    if ev is not None:
+      torch.cuda.current_stream(self._F.device).wait_event(ev)
+      self.upload_event = None
 
   @property
   def F(self):

@@ -219,3 +219,38 @@ def test_prefetch_thread_keeps_batch_order_and_reraises(built_lib):
   # fixed draws (parity tests) bypass the helper thread entirely
   tr._prefetch_start(it, {"uniform": None})
   assert tr._prefetch_thread is None
+
+
+def test_scannet_match_pair_dataset_and_infinite_loader(tmp_path):
+  """The reference's dataset class (pc/lib/ddp_data_loaders.py:119-270) on a tiny on-disk pair list: item contract,
+  correspondences within the search radius and sorted by query row; the single-GPU loader never runs dry
+  (train() calls next() far more often than len(loader))."""
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import dataset_str_mapping, make_data_loader
+  rng = np.random.RandomState(0)
+  names = []
+  for i in range(3):
+    a, b = synthetic.make_frame_pair(rng)
+    c = a[rng.randint(len(a))]
+    for tag, x in (("a", a), ("b", b)):
+      np.savez(tmp_path / ("f%d%s.npz" % (i, tag)), pcd=x[np.linalg.norm(x - c, axis=1) < 0.4])
+    names.append("f%da.npz f%db.npz 0.5\n" % (i, i))
+  (tmp_path / "pairs.txt").write_text("".join(names))
+  cfg = get_config(["data.dataset=ScanNetMatchPairDataset", "data.dataset_root_dir=%s" % tmp_path,
+                    "data.scannet_match_dir=pairs.txt", "trainer.batch_size=2", "trainer.use_random_scale=True"])
+  dset = dataset_str_mapping["ScanNetMatchPairDataset"](phase="train", config=cfg, random_scale=False)
+  xyz0, xyz1, c0, c1, f0, f1, m, trans = dset[1]
+  assert len(dset) == 3 and c0.shape == xyz0.shape and f0.shape == (len(xyz0), 3) and trans.shape == (4, 4)
+  assert len(np.unique(c0, axis=0)) == len(c0), "one point per voxel"
+  assert len(m) > 0 and (np.diff(m[:, 0]) >= 0).all()
+  d = np.linalg.norm(xyz0[m[:, 0]] @ trans[:3, :3].T + trans[:3, 3] - xyz1[m[:, 1]], axis=1)
+  assert d.max() <= 1.5 * cfg.data.voxel_size + 1e-9
+  loader = make_data_loader(cfg, cfg.trainer.batch_size)
+  it = iter(loader)
+  for _ in range(2 * len(dset)):  # > one epoch
+    batch = next(it)
+    assert batch["sinput0_C"].shape[1] == 4 and batch["sinput0_C"].dtype == torch.int32
+    assert (np.diff(batch["correspondences"][:, 0].numpy()) >= 0).all()
+  with pytest.raises(ValueError, match="does not exist"):
+    make_data_loader(get_config(["data.dataset=Nope"]), 4)
