@@ -54,6 +54,34 @@ __host__ __device__ inline uint32_t hash_key(uint64_t k) {
   return (uint32_t)k;
 }
 
+// ---- last-arriver hand-off between the workgroups of ONE launch -------------------------------------------------
+// Every workgroup of a group publishes its partial result with plain stores and then calls arrive_last() on the
+// group's counter; exactly one call (the last to arrive) returns true, and that workgroup then sees the stores of
+// all the others.  Protocol as MI355X_MICROARCH.md prescribes (per-XCD L2s are not coherent, a CU's L1 is never
+// refreshed by other CUs): plain stores -> __syncthreads -> lane-0 agent-scope RELEASE (buffer_wbl2) -> explicit
+// s_waitcnt vmcnt(0) (the compiler may drop its own) -> relaxed agent-scope ticket; the last arriver does ONE
+// agent-scope ACQUIRE (buffer_inv) -> __syncthreads -> plain loads.  The counter is left at zero (self-resetting), so
+// a zero-initialised counter pool (stream_counters, internal.h) serves every later launch on the same stream.
+// Nobody spins: correctness does not depend on which workgroups are resident.
+#if defined(__HIPCC__)
+__device__ inline bool arrive_last(unsigned* counter, unsigned expected, unsigned* s_flag /* __shared__ */) {
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (t + 1u == expected) ? 1u : 0u;
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0u;
+}
+#endif
+
 // floor division by a positive power-of-two-free divisor (coordinates may be negative)
 __host__ __device__ inline int floor_div(int a, int d) {
   int q = a / d;

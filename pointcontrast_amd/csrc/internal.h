@@ -41,6 +41,10 @@ int tile_units(const uint32_t* sorted_key, int K, int64_t n, uint32_t* tile_mask
 // rows of the contiguous tile range one XCD processes (tile swizzle of the conv kernel, 128-row tiles)
 static inline int64_t xcd_chunk_rows(int64_t n) { return ceil_div(ceil_div(n, 128), 8) * 128; }
 
+// n zero-initialised arrival counters (common.h: arrive_last) for launches on `st`: one pool per stream -- launches
+// on a stream are serialised and every kernel leaves its counters at zero.  nullptr on allocation failure.
+unsigned* stream_counters(hipStream_t st, size_t n);
+
 // compute units of the current device (cached; 256 on MI355X)
 static inline int num_cu() {
   static int n = 0;

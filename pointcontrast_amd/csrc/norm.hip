@@ -5,13 +5,47 @@
 // (per-block partials in registers + LDS, then one thread per channel combining the blocks
 // with Chan's parallel-variance update).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 #include "internal.h"
 
 namespace pcmi {
 
+// ---- per-stream arrival-counter pools (internal.h) ----------------------------------------------------------------
+unsigned* stream_counters(hipStream_t st, size_t n) {
+  struct Pool {
+    unsigned* p = nullptr;
+    size_t cap = 0;
+  };
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, Pool> pools;
+  std::lock_guard<std::mutex> lock(mu);
+  Pool& pl = pools[st];
+  if (n > pl.cap) {
+    const size_t want = std::max<size_t>(align_up(n, 4096), 16384);
+    unsigned* q = nullptr;
+    // the old pool may still be in use by a launch in flight on `st`: drain the stream before replacing it
+    // (zero-fill ON `st`: hipMemset on the null stream is not ordered against a non-blocking stream's launches)
+    if (hipStreamSynchronize(st) != hipSuccess || hipMalloc((void**)&q, want * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(q, 0, want * sizeof(unsigned), st) != hipSuccess) {
+      set_error("stream_counters: allocation of %zu counters failed", want);
+      return nullptr;
+    }
+    if (pl.p) (void)hipFree(pl.p);
+    pl.p = q;
+    pl.cap = want;
+  }
+  return pl.p;
+}
+
 constexpr int kMaxRedBlocks = 1024;
+// up to this many row blocks the statistics kernel finishes the reduction itself (last-arriving workgroup), beyond
+// it a separate one-wave-per-channel kernel does (the serial merge of the partials would be a visible tail)
+constexpr int kFuseFinalBlocks = 256;
 
 struct RedGeom {
   int c4;              // float4 columns
@@ -24,12 +58,43 @@ static RedGeom red_geom(int64_t n, int c) {
   RedGeom g;
   g.c4 = c / 4;
   g.rp = 256 / g.c4;
-  int64_t rpb = std::max<int64_t>((int64_t)g.rp * 16, ceil_div(n, kMaxRedBlocks));
+  int64_t rpb = std::max<int64_t>((int64_t)g.rp * 8, ceil_div(n, kMaxRedBlocks));
   rpb = ceil_div(rpb, g.rp) * g.rp;
   g.rows_per_block = (int)rpb;
   g.nblocks = (int)std::max<int64_t>(1, ceil_div(n, rpb));
   return g;
 }
+
+// (n, mean, M2) of a set of rows merged with another set's (Chan et al.), four channels at a time
+__device__ inline void chan_merge(float& n, float4& mean, float4& m2, float on, const float4& omean, const float4& om2) {
+  const float tot = n + on;
+  if (tot <= 0.f) return;
+  const float wa = n / tot, wb = on / tot, cross = n * on / tot;
+  const float4 d = make_float4(omean.x - mean.x, omean.y - mean.y, omean.z - mean.z, omean.w - mean.w);
+  mean = make_float4(wa * mean.x + wb * omean.x, wa * mean.y + wb * omean.y, wa * mean.z + wb * omean.z,
+                     wa * mean.w + wb * omean.w);
+  m2 = make_float4(m2.x + om2.x + d.x * d.x * cross, m2.y + om2.y + d.y * d.y * cross, m2.z + om2.z + d.z * d.z * cross,
+                   m2.w + om2.w + d.w * d.w * cross);
+  n = tot;
+}
+
+// What the last-arriving workgroup of a fused statistics launch needs to finish the reduction (counter == nullptr:
+// a separate kernel does it).
+struct RedFinal {
+  unsigned* counter;
+  // MODE 0 (BatchNorm forward statistics)
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float* save_unbiased;
+  // MODE 1 (BatchNorm backward sums)
+  float* out_a;
+  float* out_b;
+  float* acc_a;
+  float* acc_b;
+};
 
 // MODE 0: (sum x, sum x^2) per block -> (mean_b, M2_b)
 // MODE 1: (sum dy_eff, sum dy_eff * xhat)
@@ -38,9 +103,10 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld,
     const float* __restrict__ ymask, int64_t y_ld, const float* __restrict__ mean,
     const float* __restrict__ invstd, int64_t n, int c4, int rp, int rows_per_block,
-    float* __restrict__ part /* [nblocks][2][c] */) {
+    float* __restrict__ part /* [nblocks][2][c] */, RedFinal fin) {
   __shared__ float4 s_a[256];
   __shared__ float4 s_b[256];
+  __shared__ unsigned s_last;
   const int t = threadIdx.x;
   const int col = t % c4, rl = t / c4;
   const int c = c4 * 4;
@@ -53,22 +119,38 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
       mu = reinterpret_cast<const float4*>(mean)[col];
       is = reinterpret_cast<const float4*>(invstd)[col];
     }
-    for (int64_t r = r0 + rl; r < r1; r += rp) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-      if (MODE == 0) {
-        a.x += xv.x; a.y += xv.y; a.z += xv.z; a.w += xv.w;
-        b.x = fmaf(xv.x, xv.x, b.x); b.y = fmaf(xv.y, xv.y, b.y);
-        b.z = fmaf(xv.z, xv.z, b.z); b.w = fmaf(xv.w, xv.w, b.w);
-      } else {
-        float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
-        if (ymask) {
-          const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
-          g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-          g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    // rows in batches of kRowBatch: every load of a batch is issued before the first use (a row at a time was one
+    // L2 / HBM latency per row and thread -- the small-activation BatchNorms were latency-, not bandwidth-bound)
+    constexpr int kRowBatch = 4;
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)rp * kRowBatch) {
+      float4 xv[kRowBatch], gv[kRowBatch], yv[kRowBatch];
+#pragma unroll
+      for (int u = 0; u < kRowBatch; ++u) {
+        const int64_t r = rb + (int64_t)u * rp;
+        const bool ok = r < r1;
+        xv[u] = ok ? *reinterpret_cast<const float4*>(x + r * x_ld + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) {
+          gv[u] = ok ? *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ymask) yv[u] = ok ? *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
         }
-        a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-        b.x = fmaf(g.x, (xv.x - mu.x) * is.x, b.x); b.y = fmaf(g.y, (xv.y - mu.y) * is.y, b.y);
-        b.z = fmaf(g.z, (xv.z - mu.z) * is.z, b.z); b.w = fmaf(g.w, (xv.w - mu.w) * is.w, b.w);
+      }
+#pragma unroll
+      for (int u = 0; u < kRowBatch; ++u) {  // (rows past r1 were loaded as zeros: they add nothing)
+        const float4 xq = xv[u];
+        if (MODE == 0) {
+          a.x += xq.x; a.y += xq.y; a.z += xq.z; a.w += xq.w;
+          b.x = fmaf(xq.x, xq.x, b.x); b.y = fmaf(xq.y, xq.y, b.y);
+          b.z = fmaf(xq.z, xq.z, b.z); b.w = fmaf(xq.w, xq.w, b.w);
+        } else {
+          float4 g = gv[u];
+          if (ymask) {
+            g.x = yv[u].x > 0.f ? g.x : 0.f; g.y = yv[u].y > 0.f ? g.y : 0.f;
+            g.z = yv[u].z > 0.f ? g.z : 0.f; g.w = yv[u].w > 0.f ? g.w : 0.f;
+          }
+          a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+          b.x = fmaf(g.x, (xq.x - mu.x) * is.x, b.x); b.y = fmaf(g.y, (xq.y - mu.y) * is.y, b.y);
+          b.z = fmaf(g.z, (xq.z - mu.z) * is.z, b.z); b.w = fmaf(g.w, (xq.w - mu.w) * is.w, b.w);
+        }
       }
     }
   }
@@ -94,6 +176,73 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
     } else {
       reinterpret_cast<float4*>(p0)[t] = sa;
       reinterpret_cast<float4*>(p0 + c)[t] = sb;
+    }
+  }
+  // ---- fused final: the last workgroup to arrive merges the per-block partials (fixed order -> deterministic) ----
+  // Two levels, in the geometry of the main pass: thread (rl, col) folds the blocks rl, rl + rp, ... of its four
+  // channels (coalesced float4 loads, independent of each other), then the c4 column threads fold the rp lanes
+  // through LDS.  (A thread-per-channel loop over all blocks was one L2 latency per block: 20 us for 80 blocks.)
+  if (fin.counter == nullptr) return;
+  if (!arrive_last(fin.counter, gridDim.x, &s_last)) return;
+  const int nblocks = (int)gridDim.x;
+  __shared__ float s_n[256];
+  float cnt = 0.f;
+  a = make_float4(0.f, 0.f, 0.f, 0.f);  // MODE 0: running mean, MODE 1: sum a
+  b = a;                                 // MODE 0: running M2,   MODE 1: sum b
+  if (rl < rp) {
+#pragma unroll 4
+    for (int q = rl; q < nblocks; q += rp) {
+      const float4 pa = *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + col * 4);
+      const float4 pb = *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + c + col * 4);
+      if (MODE == 0) {
+        const int64_t b0 = (int64_t)q * rows_per_block;
+        chan_merge(cnt, a, b, (float)(min(b0 + (int64_t)rows_per_block, n) - b0), pa, pb);
+      } else {
+        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+      }
+    }
+  }
+  s_a[t] = a;
+  s_b[t] = b;
+  s_n[t] = cnt;
+  __syncthreads();
+  if (t >= c4) return;
+  a = s_a[t];
+  b = s_b[t];
+  cnt = s_n[t];
+  for (int q = 1; q < rp; ++q) {
+    const float4 va = s_a[q * c4 + t], vb = s_b[q * c4 + t];
+    if (MODE == 0) {
+      chan_merge(cnt, a, b, s_n[q * c4 + t], va, vb);
+    } else {
+      a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
+      b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+    }
+  }
+  if (MODE == 0) {
+    const float4 var = make_float4(b.x / cnt, b.y / cnt, b.z / cnt, b.w / cnt);
+    reinterpret_cast<float4*>(fin.save_mean)[t] = a;
+    reinterpret_cast<float4*>(fin.save_invstd)[t] = make_float4(1.0f / sqrtf(var.x + fin.eps), 1.0f / sqrtf(var.y + fin.eps),
+                                                                  1.0f / sqrtf(var.z + fin.eps), 1.0f / sqrtf(var.w + fin.eps));
+    const float ub = cnt > 1.f ? cnt / (cnt - 1.f) : 1.f;
+    const float4 unb = make_float4(var.x * ub, var.y * ub, var.z * ub, var.w * ub);
+    if (fin.save_unbiased) reinterpret_cast<float4*>(fin.save_unbiased)[t] = unb;
+    if (fin.running_mean) {
+      float4 rm = reinterpret_cast<float4*>(fin.running_mean)[t], rv = reinterpret_cast<float4*>(fin.running_var)[t];
+      const float mo = fin.momentum, om = 1.f - fin.momentum;
+      rm = make_float4(om * rm.x + mo * a.x, om * rm.y + mo * a.y, om * rm.z + mo * a.z, om * rm.w + mo * a.w);
+      rv = make_float4(om * rv.x + mo * unb.x, om * rv.y + mo * unb.y, om * rv.z + mo * unb.z, om * rv.w + mo * unb.w);
+      reinterpret_cast<float4*>(fin.running_mean)[t] = rm;
+      reinterpret_cast<float4*>(fin.running_var)[t] = rv;
+    }
+  } else {
+    reinterpret_cast<float4*>(fin.out_a)[t] = a;
+    reinterpret_cast<float4*>(fin.out_b)[t] = b;
+    if (fin.acc_a) {
+      float4 ga = reinterpret_cast<float4*>(fin.acc_a)[t], gb = reinterpret_cast<float4*>(fin.acc_b)[t];
+      reinterpret_cast<float4*>(fin.acc_a)[t] = make_float4(ga.x + a.x, ga.y + a.y, ga.z + a.z, ga.w + a.w);
+      reinterpret_cast<float4*>(fin.acc_b)[t] = make_float4(gb.x + b.x, gb.y + b.y, gb.z + b.z, gb.w + b.w);
     }
   }
 }
@@ -308,160 +457,12 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a
   *reinterpret_cast<float4*>(out + r * out_ld + sub * 4) = o;
 }
 
-// ---- small activations (n <= kSmallRows: the whole tensor sits in L2): statistics + normalisation in ONE
-// launch, one workgroup per float4 channel column.  Replaces three launches (partial, final, apply) whose
-// run time at these sizes is pure launch latency; used by 44 of the 62 BatchNorms of Res16UNet34C.
-constexpr int64_t kSmallRows = 8192;
-constexpr int kSmallThreads = 1024;  // 16 waves per channel column: the two passes are latency-, not bandwidth-bound
-
-__device__ inline void chan_merge(float& n, float4& mean, float4& m2, float on, const float4& omean, const float4& om2) {
-  const float tot = n + on;
-  if (tot <= 0.f) return;
-  const float wa = n / tot, wb = on / tot, cross = n * on / tot;
-  float4 d = make_float4(omean.x - mean.x, omean.y - mean.y, omean.z - mean.z, omean.w - mean.w);
-  mean = make_float4(wa * mean.x + wb * omean.x, wa * mean.y + wb * omean.y, wa * mean.z + wb * omean.z,
-                     wa * mean.w + wb * omean.w);
-  m2 = make_float4(m2.x + om2.x + d.x * d.x * cross, m2.y + om2.y + d.y * d.y * cross, m2.z + om2.z + d.z * d.z * cross,
-                   m2.w + om2.w + d.w * d.w * cross);
-  n = tot;
-}
-
-__global__ __launch_bounds__(kSmallThreads) void bn_small_fwd_kernel(const float* __restrict__ x, int64_t x_ld, int64_t n,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                           float momentum, float eps, const float* __restrict__ res,
-                                                           int64_t res_ld, int relu, float* __restrict__ y, int64_t y_ld,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                           float* __restrict__ save_unbiased) {
-  __shared__ float s_n[kSmallThreads];
-  __shared__ float4 s_mean[kSmallThreads];
-  __shared__ float4 s_m2[kSmallThreads];
-  const int t = threadIdx.x, col = blockIdx.x;
-  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
-  float cnt = 0.f;
-  for (int64_t r = t; r < n; r += kSmallThreads) {
-    const float4 v = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-    sq.x = fmaf(v.x, v.x, sq.x); sq.y = fmaf(v.y, v.y, sq.y); sq.z = fmaf(v.z, v.z, sq.z); sq.w = fmaf(v.w, v.w, sq.w);
-    cnt += 1.f;
-  }
-  float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), m2 = mean;
-  if (cnt > 0.f) {
-    mean = make_float4(sum.x / cnt, sum.y / cnt, sum.z / cnt, sum.w / cnt);
-    m2 = make_float4(fmaxf(sq.x - sum.x * mean.x, 0.f), fmaxf(sq.y - sum.y * mean.y, 0.f), fmaxf(sq.z - sum.z * mean.z, 0.f),
-                     fmaxf(sq.w - sum.w * mean.w, 0.f));
-  }
-  s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
-  __syncthreads();
-  for (int d = kSmallThreads / 2; d >= 1; d >>= 1) {
-    if (t < d) {
-      chan_merge(cnt, mean, m2, s_n[t + d], s_mean[t + d], s_m2[t + d]);
-      s_n[t] = cnt; s_mean[t] = mean; s_m2[t] = m2;
-    }
-    __syncthreads();
-  }
-  cnt = s_n[0]; mean = s_mean[0]; m2 = s_m2[0];
-  const float4 var = make_float4(m2.x / cnt, m2.y / cnt, m2.z / cnt, m2.w / cnt);
-  const float4 is = make_float4(1.0f / sqrtf(var.x + eps), 1.0f / sqrtf(var.y + eps), 1.0f / sqrtf(var.z + eps),
-                                1.0f / sqrtf(var.w + eps));
-  if (t == 0) {
-    reinterpret_cast<float4*>(save_mean)[col] = mean;
-    reinterpret_cast<float4*>(save_invstd)[col] = is;
-    const float ub = cnt > 1.f ? cnt / (cnt - 1.f) : 1.f;
-    if (save_unbiased)
-      reinterpret_cast<float4*>(save_unbiased)[col] = make_float4(var.x * ub, var.y * ub, var.z * ub, var.w * ub);
-    if (running_mean) {
-      float4 rm = reinterpret_cast<float4*>(running_mean)[col], rv = reinterpret_cast<float4*>(running_var)[col];
-      const float om = 1.f - momentum;
-      rm = make_float4(om * rm.x + momentum * mean.x, om * rm.y + momentum * mean.y, om * rm.z + momentum * mean.z,
-                       om * rm.w + momentum * mean.w);
-      rv = make_float4(om * rv.x + momentum * var.x * ub, om * rv.y + momentum * var.y * ub, om * rv.z + momentum * var.z * ub,
-                       om * rv.w + momentum * var.w * ub);
-      reinterpret_cast<float4*>(running_mean)[col] = rm;
-      reinterpret_cast<float4*>(running_var)[col] = rv;
-    }
-  }
-  const float4 g = reinterpret_cast<const float4*>(gamma)[col], b = reinterpret_cast<const float4*>(beta)[col];
-  for (int64_t r = t; r < n; r += kSmallThreads) {
-    const float4 v = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-    float4 o = make_float4((v.x - mean.x) * is.x * g.x + b.x, (v.y - mean.y) * is.y * g.y + b.y,
-                           (v.z - mean.z) * is.z * g.z + b.z, (v.w - mean.w) * is.w * g.w + b.w);
-    if (res) {
-      const float4 rv = *reinterpret_cast<const float4*>(res + r * res_ld + col * 4);
-      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
-    }
-    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-    *reinterpret_cast<float4*>(y + r * y_ld + col * 4) = o;
-  }
-}
-
-__global__ __launch_bounds__(kSmallThreads) void bn_small_bwd_kernel(
-    const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t x_ld,
-    const float* __restrict__ ymask, int64_t y_ld, int64_t n, const float* __restrict__ gamma,
-    const float* __restrict__ mean_p, const float* __restrict__ invstd_p, float* __restrict__ dx, int64_t dx_ld,
-    float* __restrict__ dres, int64_t dres_ld, int dres_accumulate, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ acc_dgamma, float* __restrict__ acc_dbeta) {
-  __shared__ float4 s_a[kSmallThreads];
-  __shared__ float4 s_b[kSmallThreads];
-  const int t = threadIdx.x, col = blockIdx.x;
-  const float4 mu = reinterpret_cast<const float4*>(mean_p)[col], is = reinterpret_cast<const float4*>(invstd_p)[col];
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-  for (int64_t r = t; r < n; r += kSmallThreads) {
-    float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
-    if (ymask) {
-      const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
-      g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
-    }
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
-    b.x = fmaf(g.x, (xv.x - mu.x) * is.x, b.x); b.y = fmaf(g.y, (xv.y - mu.y) * is.y, b.y);
-    b.z = fmaf(g.z, (xv.z - mu.z) * is.z, b.z); b.w = fmaf(g.w, (xv.w - mu.w) * is.w, b.w);
-  }
-  s_a[t] = a; s_b[t] = b;
-  __syncthreads();
-  for (int d = kSmallThreads / 2; d >= 1; d >>= 1) {
-    if (t < d) {
-      const float4 oa = s_a[t + d], ob = s_b[t + d];
-      a = make_float4(a.x + oa.x, a.y + oa.y, a.z + oa.z, a.w + oa.w);
-      b = make_float4(b.x + ob.x, b.y + ob.y, b.z + ob.z, b.w + ob.w);
-      s_a[t] = a; s_b[t] = b;
-    }
-    __syncthreads();
-  }
-  const float4 sg = s_a[0], sx = s_b[0];
-  if (t == 0) {
-    reinterpret_cast<float4*>(dbeta)[col] = sg;
-    reinterpret_cast<float4*>(dgamma)[col] = sx;
-    if (acc_dbeta) {
-      float4 ab = reinterpret_cast<float4*>(acc_dbeta)[col], ag = reinterpret_cast<float4*>(acc_dgamma)[col];
-      reinterpret_cast<float4*>(acc_dbeta)[col] = make_float4(ab.x + sg.x, ab.y + sg.y, ab.z + sg.z, ab.w + sg.w);
-      reinterpret_cast<float4*>(acc_dgamma)[col] = make_float4(ag.x + sx.x, ag.y + sx.y, ag.z + sx.z, ag.w + sx.w);
-    }
-  }
-  const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
-  const float inv_n = 1.0f / (float)n;
-  for (int64_t r = t; r < n; r += kSmallThreads) {
-    float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
-    if (ymask) {
-      const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
-      g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
-    }
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-    float4 o;
-    o.x = ga.x * is.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * is.x * sx.x * inv_n);
-    o.y = ga.y * is.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * is.y * sx.y * inv_n);
-    o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
-    o.w = ga.w * is.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * is.w * sx.w * inv_n);
-    *reinterpret_cast<float4*>(dx + r * dx_ld + col * 4) = o;
-    if (dres) {
-      float4* dp = reinterpret_cast<float4*>(dres + r * dres_ld + col * 4);
-      if (dres_accumulate) {
-        const float4 old = *dp;
-        g = make_float4(g.x + old.x, g.y + old.y, g.z + old.z, g.w + old.w);
-      }
-      *dp = g;
-    }
-  }
+static bool fuse_final_enabled() {  // PCMI_BN_FUSE_FINAL=0: always the separate final kernels (A/B, debugging)
+  static const bool on = [] {
+    const char* e = getenv("PCMI_BN_FUSE_FINAL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 static int check_rows(const char* who, const void* p, int64_t ld, int c) {
@@ -510,21 +511,31 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
   if (residual && (rc = check_rows("bn_fwd_train(residual)", residual, res_ld, c))) return rc;
   PCMI_REQUIRE(gamma && beta && save_mean && save_invstd && n > 0 && c <= 1024, PCMI_ERR_INVALID, "bn_fwd_train: bad argument");
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_fwd_train: workspace too small");
-  if (n <= kSmallRows) {
-    bn_small_fwd_kernel<<<c / 4, kSmallThreads, 0, st>>>(x, x_ld, n, gamma, beta, running_mean, running_var, momentum, eps, residual, res_ld,
-                                               relu, y, y_ld, save_mean, save_invstd, save_unbiased);
-    PCMI_LAUNCH_CHECK();
-    return PCMI_OK;
-  }
   const RedGeom g = red_geom(n, c);
   float* part = (float*)ws;
+  RedFinal fin;
+  memset(&fin, 0, sizeof(fin));
+  const bool fuse = g.nblocks <= kFuseFinalBlocks && fuse_final_enabled();
+  if (fuse) {  // statistics + their final merge in ONE launch (last-arriving workgroup), then the apply pass
+    fin.counter = stream_counters(st, 1);
+    if (!fin.counter) return PCMI_ERR_HIP;
+    fin.eps = eps;
+    fin.momentum = momentum;
+    fin.running_mean = running_mean;
+    fin.running_var = running_var;
+    fin.save_mean = save_mean;
+    fin.save_invstd = save_invstd;
+    fin.save_unbiased = save_unbiased;
+  }
   colreduce_partial_kernel<0><<<g.nblocks, 256, 0, st>>>(x, x_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, n, g.c4, g.rp,
-                                                        g.rows_per_block, part);
+                                                        g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
-  bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
-                                                                       running_mean, running_var, save_mean, save_invstd,
-                                                                       save_unbiased);
-  PCMI_LAUNCH_CHECK();
+  if (!fuse) {
+    bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
+                                                                         running_mean, running_var, save_mean, save_invstd,
+                                                                         save_unbiased);
+    PCMI_LAUNCH_CHECK();
+  }
   bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
                                                         res_ld, relu, y, y_ld);
   PCMI_LAUNCH_CHECK();
@@ -584,19 +595,26 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   if (dres && (rc = check_rows("bn_bwd(dres)", dres, dres_ld, c))) return rc;
   PCMI_REQUIRE(gamma && save_mean && save_invstd && dgamma && dbeta && n > 0, PCMI_ERR_INVALID, "bn_bwd: bad argument");
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_bwd: workspace too small");
-  if (n <= kSmallRows) {
-    bn_small_bwd_kernel<<<c / 4, kSmallThreads, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, gamma, save_mean, save_invstd, dx, dx_ld,
-                                               dres, dres_ld, dres_accumulate, dgamma, dbeta, acc_dgamma, acc_dbeta);
-    PCMI_LAUNCH_CHECK();
-    return PCMI_OK;
-  }
   const RedGeom g = red_geom(n, c);
   float* part = (float*)ws;
+  RedFinal fin;
+  memset(&fin, 0, sizeof(fin));
+  const bool fuse = g.nblocks <= kFuseFinalBlocks && fuse_final_enabled();
+  if (fuse) {
+    fin.counter = stream_counters(st, 1);
+    if (!fin.counter) return PCMI_ERR_HIP;
+    fin.out_a = dbeta;
+    fin.out_b = dgamma;
+    fin.acc_a = acc_dbeta;
+    fin.acc_b = acc_dgamma;
+  }
   colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
-                                                        g.c4, g.rp, g.rows_per_block, part);
+                                                        g.c4, g.rp, g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
-  colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
-  PCMI_LAUNCH_CHECK();
+  if (!fuse) {
+    colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
+    PCMI_LAUNCH_CHECK();
+  }
   bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
                                                             save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld, dres_accumulate);
   PCMI_LAUNCH_CHECK();

@@ -430,6 +430,259 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   }  // for (;;)
 }
 
+// ---- 16-row variant for the 128-row tiles ------------------------------------------------------------------------
+// Same formulation, operands and LDS staging as spconv_mfma_kernel<NT, 4, WT, false, SK>, but on
+// v_mfma_f32_16x16x4_f32 (same peak): lane l = (i = l & 15, kk = l >> 4) supplies A[i][kk] and B[kk][j = i].  A wave
+// still owns 32 rows, now as TWO independent 16-row groups, and skips an offset per GROUP: with 32-row groups the
+// matrix pipe issued 1.18x the algorithmic FLOPs on the mask-sorted level-1 maps (PMC), the zero rows of waves whose
+// 32 rows are only partly present at an offset.  The float4 a lane gathers (channels c0 + 16 blk + 4 kk .. +3 of its
+// row: the four kk lanes of a row read 64 contiguous bytes) feeds four consecutive MFMA steps; step s contracts the
+// channels {c0 + 16 blk + 4 kk + s}, and the B fragment uses the same bijection.  One B fragment (ds_read_b32, 2 NT
+// per step) serves both row groups.  LDB = NS + 4 keeps those reads bank-conflict free (4 LDB = 16 mod 32).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, bool WT, bool SK>
+__global__ __launch_bounds__(256, 3) void spconv16_kernel(ConvArgs a) {
+  constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
+  constexpr int LDB = NS + 4;
+  constexpr int KSLOTS = PCMI_MAX_KERNEL_VOLUME;
+  __shared__ __attribute__((aligned(16))) float s_f[2 * kKC * LDB];
+  __shared__ int32_t s_idx[KSLOTS][TM];
+  __shared__ int32_t s_orow[TM];
+  __shared__ int32_t s_klist[KSLOTS];
+  __shared__ int32_t s_kabs[KSLOTS];
+  __shared__ int32_t s_nk;
+  __shared__ int64_t s_tile[2];
+
+  const int n0 = blockIdx.y * NS;
+  int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
+  bool sk_first = true;
+  if constexpr (SK) {
+    const int G = (int)gridDim.x;
+    sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
+    const int U = a.sk_pref[a.sk_tiles];
+    const int per = (U + G - 1) / G;
+    sk_u = sk_g * per;
+    sk_u1 = min(U, sk_u + per);
+    if (sk_u >= sk_u1) return;
+    if (threadIdx.x == 0) {
+      int lo = 0, hi = a.sk_tiles - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.sk_pref[mid] <= sk_u) lo = mid; else hi = mid - 1;
+      }
+      s_tile[0] = lo;
+    }
+    __syncthreads();
+    sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);
+  }
+  for (;;) {  // one pass per tile piece (exactly one when !SK)
+  bool sk_whole = true;
+  int sk_next_u = 0;
+  int t = threadIdx.x;
+  if constexpr (SK) asm volatile("" : "+v"(t));  // see spconv_mfma_kernel
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  int kbeg = 0;
+  if constexpr (SK) {
+    const int64_t row0 = (int64_t)sk_tile * TM;
+    const uint32_t tmask = a.sk_mask[sk_tile];
+    const int pref = a.sk_pref[sk_tile], nk_t = __popc(tmask);
+    const int jb = sk_u - pref, je = min(sk_u1 - pref, nk_t);
+    sk_whole = (jb == 0 && je == nk_t);
+    sk_next_u = pref + je;
+    if (t == 0) {
+      int j = 0, c = 0;
+      for (int k = 0; k < a.K; ++k)
+        if ((tmask >> k) & 1u) {
+          if (j >= jb && j < je) {
+            s_kabs[c] = k;
+            s_klist[c] = c;
+            ++c;
+          }
+          ++j;
+        }
+      s_nk = c;
+    }
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    __syncthreads();
+    const int cnt = je - jb;
+    for (int p = t; p < cnt * TM; p += 256) {
+      const int q = p / TM, rr = p - q * TM;
+      const int64_t row = row0 + rr;
+      s_idx[q][rr] = row < a.n_rows ? a.nbr[(int64_t)s_kabs[q] * a.n_rows + row] : -1;
+    }
+  } else {
+    int64_t tile = blockIdx.x;
+    if (a.xcd_tiles > 0) {
+      tile = (int64_t)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
+      if (tile * TM >= a.n_rows) return;
+    }
+    const int64_t row0 = tile * TM;
+    kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
+    const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    for (int p = t; p < (kend - kbeg) * TM; p += 256) {
+      const int q = p / TM, rr = p - q * TM;
+      const int64_t row = row0 + rr;
+      int32_t v = -1;
+      if (row < a.n_rows) v = a.nbr ? a.nbr[(int64_t)(kbeg + q) * a.n_rows + row] : (int32_t)row;
+      s_idx[q][rr] = v;
+    }
+    __syncthreads();
+    if (t < 64) {  // offsets with at least one neighbour in this tile
+      int nk = 0;
+      for (int q = 0; q < kend - kbeg; ++q) {
+        bool any = false;
+        for (int rr = t; rr < TM; rr += 64) any |= (s_idx[q][rr] >= 0);
+        if (__any(any)) {
+          if (t == 0) s_klist[nk] = q;
+          ++nk;
+        }
+      }
+      if (t == 0) s_nk = nk;
+    }
+  }
+  __syncthreads();
+  const int nk = s_nk;
+  const int nch = a.C / kKC;
+  const int nsteps = nk * nch;
+
+  f32x4 acc[2][CTN];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int ct = 0; ct < CTN; ++ct) acc[g][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  v4f breg[NT];
+  auto load_b = [&](int step) {
+    const int kslot = s_klist[step / nch];
+    const int c0 = (step % nch) * kKC;
+    const int wk = SK ? a.wsel[s_kabs[kslot]] : a.wsel[kbeg + kslot];
+    load_b_regs<NT, WT>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
+  };
+  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
+  // A: [group][16-channel block] float4 of this lane's row, one 32-channel step ahead; va: which groups have a row
+  float4 a0[2][2], a1[2][2];
+  int va0 = 0, va1 = 0;
+  auto load_a = [&](int step, float4 (&dst)[2][2]) -> int {
+    const int kslot = s_klist[step / nch];
+    const int c0 = (step % nch) * kKC;
+    int valid = 0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int32_t idx = s_idx[kslot][wave * 32 + g * 16 + i];
+      if (idx >= 0) {
+        const float* xp = a.x + (int64_t)idx * a.x_ld + c0 + 4 * kk;
+        dst[g][0] = *reinterpret_cast<const float4*>(xp);
+        dst[g][1] = *reinterpret_cast<const float4*>(xp + 16);
+      } else {
+        dst[g][0] = dst[g][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      valid |= __any(idx >= 0) ? (1 << g) : 0;
+    }
+    return valid;
+  };
+
+  if (nsteps > 0) {
+    load_b(0);
+    va0 = load_a(0, a0);
+    store_b(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+      const bool more = step + 1 < nsteps;
+      if (more) load_b(step + 1);
+      if (more) va1 = load_a(step + 1, a1);
+      if (va0) {
+        // B fragments PF contraction steps ahead of their MFMAs (register ring, order pinned by sched_barrier)
+        const float* sb = s_f + (step & 1) * (kKC * LDB) + i + (4 * kk) * LDB;
+        constexpr int QN = 8, PF = 2;  // 8 contraction steps of 4 channels per lane-quad; >= 256 NT cycles ahead
+        float bf[PF][CTN];
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+          for (int ct = 0; ct < CTN; ++ct) bf[q][ct] = sb[(16 * (q >> 2) + (q & 3)) * LDB + ct * 16];
+        __builtin_amdgcn_sched_barrier(0);
+        const bool g0 = (va0 & 1) != 0, g1 = (va0 & 2) != 0;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const float4 x0 = a0[0][q >> 2], x1 = a0[1][q >> 2];
+          const float av0 = (q & 3) == 0 ? x0.x : (q & 3) == 1 ? x0.y : (q & 3) == 2 ? x0.z : x0.w;
+          const float av1 = (q & 3) == 0 ? x1.x : (q & 3) == 1 ? x1.y : (q & 3) == 2 ? x1.z : x1.w;
+          if (g0) {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct)
+              acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bf[q % PF][ct], acc[0][ct], 0, 0, 0);
+          }
+          if (g1) {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct)
+              acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bf[q % PF][ct], acc[1][ct], 0, 0, 0);
+          }
+          if (q + PF < QN) {
+            const int qq = q + PF;
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) bf[q % PF][ct] = sb[(16 * (qq >> 2) + (qq & 3)) * LDB + ct * 16];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (more) store_b((step + 1) & 1);
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        a0[g][0] = a1[g][0];
+        a0[g][1] = a1[g][1];
+      }
+      va0 = va1;
+    }
+  }
+
+  // ---- epilogue: D[row = 4 kk + r][col = i] of every 16x16 tile --------------------------------------------------
+  if (SK && !sk_whole) {
+    float* pp = a.sk_part + ((int64_t)(2 * sk_g + (sk_first ? 0 : 1)) * TM + wave * 32) * a.N + n0 + i;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = g * 16 + 4 * kk + r;
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) pp[(int64_t)rl * a.N + ct * 16] = acc[g][ct][r];
+      }
+  } else {
+    float* outp = a.out + (int64_t)blockIdx.z * a.split_stride;
+    float bv[CTN];
+#pragma unroll
+    for (int ct = 0; ct < CTN; ++ct) bv[ct] = a.bias ? a.bias[n0 + ct * 16 + i] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int32_t orow = s_orow[wave * 32 + g * 16 + 4 * kk + r];
+        if (orow >= 0) {
+          float* op = outp + (int64_t)orow * a.out_ld + n0 + i;
+          if (a.accumulate) {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] += acc[g][ct][r] + bv[ct];
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] = acc[g][ct][r] + bv[ct];
+          }
+        }
+      }
+  }
+  if constexpr (!SK) {
+    break;
+  } else {
+    sk_u = sk_next_u;
+    ++sk_tile;
+    sk_first = false;
+    if (sk_u >= sk_u1) break;
+    __syncthreads();
+  }
+  }  // for (;;)
+}
+
 // Sums the pieces of the tiles that the SK launch split between workgroups (see spconv_mfma_kernel) into the
 // output rows, in workgroup order.  One workgroup per tile; tiles written whole by one workgroup are skipped.
 __global__ __launch_bounds__(256) void sk_fixup_kernel(const float* __restrict__ part, const int32_t* __restrict__ pref,
@@ -486,13 +739,22 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, int64_t spli
   if (idx >= n_rows * n4) return;
   const int64_t row = idx / n4;
   const int c = (int)(idx % n4) * 4;
-  float4 s = *reinterpret_cast<const float4*>(part + row * N + c);
-  for (int i = 1; i < ksplit; ++i) {
-    const float4 v = *reinterpret_cast<const float4*>(part + i * split_stride + row * N + c);
-    s.x += v.x;
-    s.y += v.y;
-    s.z += v.z;
-    s.w += v.w;
+  // partials in batches of 8: all loads of a batch are in flight together (one dependent load per partial was a
+  // chain of up to 27 L2 latencies); the additions stay in partial order -> same sums as before, deterministic
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i0 = 0; i0 < ksplit; i0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = i0 + u < ksplit ? *reinterpret_cast<const float4*>(part + (int64_t)(i0 + u) * split_stride + row * N + c)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s.x += v[u].x;
+      s.y += v[u].y;
+      s.z += v[u].z;
+      s.w += v[u].w;
+    }
   }
   if (bias) {
     s.x += bias[c];
@@ -573,6 +835,28 @@ static bool sk_rows_eligible(int64_t rows, int K) {
 }
 static size_t sk_partial_bytes(int64_t rows, int N, int K) {
   return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups() * 2 * 128 * N * sizeof(float) : 0;
+}
+
+// The 16-row kernel takes the 128-row tiles of levels with at least PCMI_CONV16 rows (default 8192; 0 = never, 1 =
+// always).  Measured (scripts/kbench.py): level 2 (20k rows) 3-5 % faster, level 1 equal, the <= 5k-row levels
+// 3-9 % slower (their NT = 1 / offset-split launches are latency-, not matrix-bound).
+static bool conv16_enabled(int64_t n_rows) {
+  const char* e = getenv("PCMI_CONV16");
+  const int64_t min_rows = e ? atoll(e) : 8192;
+  return min_rows > 0 && n_rows >= min_rows;
+}
+
+template <bool WT, bool SK>
+static int launch16(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  switch (NT) {
+    case 1: spconv16_kernel<1, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 2: spconv16_kernel<2, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 3: spconv16_kernel<3, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 4: spconv16_kernel<4, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
+  }
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
 }
 
 template <int RW, bool WT, bool PAIR>
@@ -713,7 +997,11 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
     a.sk_tiles = (int)map->n_tiles;
     a.sk_part = (float*)ws;
     dim3 grid((unsigned)G, (unsigned)(N / (32 * p.NT)), 1);
-    int rc = w_transposed ? launch_sk<true>(p.NT, a, grid, st) : launch_sk<false>(p.NT, a, grid, st);
+    int rc;
+    if (conv16_enabled(n_rows))
+      rc = w_transposed ? launch16<true, true>(p.NT, a, grid, st) : launch16<false, true>(p.NT, a, grid, st);
+    else
+      rc = w_transposed ? launch_sk<true>(p.NT, a, grid, st) : launch_sk<false>(p.NT, a, grid, st);
     if (rc) return rc;
     sk_fixup_kernel<<<dim3((unsigned)a.sk_tiles), 256, 0, st>>>(a.sk_part, a.sk_pref, a.sk_tiles, G, a.perm, n_rows, N, bias,
                                                               out, out_ld, accumulate);
@@ -736,8 +1024,11 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
     tiles = (int64_t)a.xcd_tiles * 8;
   }
   dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
-  int rc = w_transposed ? launch_rw<true, false>(p.RW, p.NT, a, grid, st)
-                        : launch_rw<false, false>(p.RW, p.NT, a, grid, st);
+  int rc;
+  if (p.RW == 4 && conv16_enabled(n_rows))
+    rc = w_transposed ? launch16<true, false>(p.NT, a, grid, st) : launch16<false, false>(p.NT, a, grid, st);
+  else
+    rc = w_transposed ? launch_rw<true, false>(p.RW, p.NT, a, grid, st) : launch_rw<false, false>(p.RW, p.NT, a, grid, st);
   if (rc) return rc;
   if (p.ksplit > 1) {
     const int64_t n4 = n_rows * (N / 4);

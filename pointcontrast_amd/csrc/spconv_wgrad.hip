@@ -12,6 +12,7 @@
 // summed through LDS, and the workgroup writes one [32*CT x 32*NT] slab; a second kernel sums
 // the slabs of each offset in fixed order (deterministic, no float atomics).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "internal.h"
@@ -33,7 +34,17 @@ struct WgradArgs {
   int cin, cout;
   int chunk;        // pairs per workgroup (multiple of 256)
   float* slabs;     // [n_chunks][cin][cout]
+  // how the chunks of an offset become gW[k] (chosen on the host from the per-offset chunk counts):
+  //   kSlabs  : every workgroup writes its slab, wgrad_reduce_kernel sums them (many chunks per offset: level 1)
+  //   kDirect : no offset has more than one chunk -> the workgroup stores / accumulates straight into gW (levels 4+)
+  //   kArrive : a few chunks per offset -> slabs + the last-arriving workgroup of the (offset, tile) sums them in
+  //             chunk order (deterministic) and writes gW; no second launch
+  int mode;
+  float* gw;        // [K][cin][cout]
+  int accumulate;
+  unsigned* counters;  // kArrive: one per (offset, tile-y, tile-z), zero on entry and on exit
 };
+enum { kSlabs = 0, kDirect = 1, kArrive = 2 };
 
 template <int V>
 struct VecLoad;
@@ -70,15 +81,19 @@ struct VecLoad<4> {
   }
 };
 
-// chunk c of the launch -> (offset k, first pair, last pair)
+// chunk c of the launch -> (offset k, first pair, last pair); first_chunk / n_chunks: the chunks of that offset
 __device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int chunk, int64_t c,
-                                    int* k_out, int64_t* pb, int64_t* pe) {
+                                    int* k_out, int64_t* pb, int64_t* pe, int64_t* first_chunk = nullptr,
+                                    int64_t* n_chunks = nullptr) {
   if (!offs) {
     *k_out = 0;
     *pb = c * chunk;
     *pe = min(*pb + (int64_t)chunk, M);
+    if (first_chunk) *first_chunk = 0;
+    if (n_chunks) *n_chunks = (M + chunk - 1) / chunk;
     return;
   }
+  int64_t first = 0;
   for (int k = 0; k < K; ++k) {
     const int64_t b = offs[k], e = offs[k + 1];
     const int64_t nc = (e - b + chunk - 1) / chunk;
@@ -86,9 +101,12 @@ __device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int c
       *k_out = k;
       *pb = b + c * chunk;
       *pe = min(*pb + (int64_t)chunk, e);
+      if (first_chunk) *first_chunk = first;
+      if (n_chunks) *n_chunks = nc;
       return;
     }
     c -= nc;
+    first += nc;
   }
   *k_out = -1;
   *pb = *pe = 0;
@@ -98,17 +116,20 @@ template <int CT, int NT, bool IDX>
 // min 2 waves/SIMD keeps the 9 accumulator tiles in VGPRs (198 registers); unbounded, hipcc used 190 + 144 AGPRs = 1 wave/SIMD
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   __shared__ float s_red[32 * CT][32 * NT + 1];
-  __shared__ int64_t s_desc[3];
+  __shared__ int64_t s_desc[5];
+  __shared__ unsigned s_last;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int c0 = blockIdx.y * 32 * CT, n0 = blockIdx.z * 32 * NT;
   if (t == 0) {
     int k;
-    int64_t pb, pe;
-    locate_chunk(a.offs, a.K, a.M, a.chunk, blockIdx.x, &k, &pb, &pe);
+    int64_t pb, pe, fc, nc;
+    locate_chunk(a.offs, a.K, a.M, a.chunk, blockIdx.x, &k, &pb, &pe, &fc, &nc);
     s_desc[0] = k;
     s_desc[1] = pb;
     s_desc[2] = pe;
+    s_desc[3] = fc;
+    s_desc[4] = nc;
   }
   __syncthreads();
   if (s_desc[0] < 0) return;
@@ -230,8 +251,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     }
     __syncthreads();
   }
+  // ---- write-out: the summed tile goes through LDS so that all 256 threads store (or accumulate) it, coalesced
+  // along cout, with every read of a read-modify-write issued before the first store ---------------------------
+  const int64_t per_k = (int64_t)a.cin * a.cout;
+  const int k_off = (int)s_desc[0];
+  constexpr int TW = 32 * NT, TE = 32 * CT * TW, EPT = TE / 256;  // tile width, elements, elements per thread
   if (wave == 0) {
-    float* slab = a.slabs + (int64_t)blockIdx.x * a.cin * a.cout;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -240,10 +265,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
         for (int j = 0; j < 16; ++j) {
           // tile (ct, nt): row = lane index of the A role (cin), col = lane index i of the B role (cout)
           const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-          const int c = c0 + CT * row + ct, n = n0 + NT * i + nt;
-          slab[(int64_t)c * a.cout + n] = acc[ct][nt][j];
+          s_red[CT * row + ct][NT * i + nt] = acc[ct][nt][j];
         }
   }
+  __syncthreads();
+  const bool direct = a.mode == kDirect;
+  float* base = direct ? a.gw + (int64_t)k_off * per_k : a.slabs + (int64_t)blockIdx.x * per_k;
+  float v[EPT];
+  int64_t el[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = t + 256 * j, r = e / TW, col = e - r * TW;
+    el[j] = (int64_t)(c0 + r) * a.cout + n0 + col;
+    v[j] = s_red[r][col];
+  }
+  if (direct && a.accumulate) {
+    float old[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) old[j] = base[el[j]];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) v[j] += old[j];
+  }
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) base[el[j]] = v[j];
+  if (a.mode != kArrive) return;
+  // ---- the last workgroup of this (offset, tile) to arrive sums the slabs in chunk order -------------------------
+  const int64_t first = s_desc[3], count = s_desc[4];
+  unsigned* counter = a.counters + ((int64_t)k_off * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  if (!arrive_last(counter, (unsigned)count, &s_last)) return;
+  float sum[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) sum[j] = 0.f;
+  for (int64_t q = 0; q < count; ++q) {  // chunk order (deterministic); EPT independent loads in flight per chunk
+    const float* sl = a.slabs + (first + q) * per_k;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) sum[j] += sl[el[j]];
+  }
+  float* dst = a.gw + (int64_t)k_off * per_k;
+  if (a.accumulate) {
+    float old[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) old[j] = dst[el[j]];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) sum[j] += old[j];
+  }
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) dst[el[j]] = sum[j];
 }
 
 // gW[k][e] = sum over the chunks of offset k of slab[chunk][e] (fixed order -> deterministic).
@@ -519,7 +586,31 @@ int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
   }
   a.chunk = wgrad_chunk(map, M, wgs_per_chunk, slots);
   const int64_t nchunks = wgrad_num_chunks(map, M, a.chunk);
-  const size_t slab_bytes = (size_t)nchunks * per_k * sizeof(float);
+  int64_t max_per_k = 0, empty_k = 0;  // chunks of the busiest offset, offsets without pairs
+  for (int k = 0; k < K; ++k) {
+    const int64_t len = map ? map->offs_host[k + 1] - map->offs_host[k] : M;
+    max_per_k = std::max(max_per_k, ceil_div(len, a.chunk));
+    empty_k += len == 0;
+  }
+  static const int arrive_max = [] {  // PCMI_WGRAD_ARRIVE_MAX: most chunks per offset the in-kernel reduction takes
+    const char* e = getenv("PCMI_WGRAD_ARRIVE_MAX");
+    return e ? atoi(e) : 8;
+  }();
+  static const bool direct_ok = [] {  // PCMI_WGRAD_DIRECT=0: always go through slabs (A/B, debugging)
+    const char* e = getenv("PCMI_WGRAD_DIRECT");
+    return !(e && e[0] == '0');
+  }();
+  a.mode = stem ? kSlabs : (max_per_k <= 1 && direct_ok ? kDirect : (max_per_k <= arrive_max ? kArrive : kSlabs));
+  a.gw = gweight;
+  a.accumulate = accumulate;
+  a.counters = nullptr;
+  if (a.mode == kArrive) {
+    a.counters = stream_counters(st, (size_t)K * (cin / (32 * CT)) * (cout / (32 * NT)));
+    if (!a.counters) return PCMI_ERR_HIP;
+  }
+  if (a.mode != kSlabs && empty_k > 0 && !accumulate)  // offsets without pairs get no workgroup: their slices are zero
+    PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
+  const size_t slab_bytes = a.mode == kDirect ? 0 : (size_t)nchunks * per_k * sizeof(float);
   const size_t bias_bytes = gbias ? (size_t)1024 * cout * sizeof(float) : 0;
   PCMI_REQUIRE(ws && ws_bytes >= slab_bytes + bias_bytes, PCMI_ERR_WORKSPACE,
                "spconv_bwd_weight: workspace %zu < %zu bytes", ws_bytes, slab_bytes + bias_bytes);
@@ -537,7 +628,9 @@ int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
     }
     if (rc) return rc;
   }
-  if (nchunks > 16 * (int64_t)K)
+  if (a.mode != kSlabs) {
+    // gW is complete when the launch is
+  } else if (nchunks > 16 * (int64_t)K)
     wgrad_reduce_kernel<8><<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
                                                                                           per_k, gweight, accumulate);
   else

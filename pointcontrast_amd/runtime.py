@@ -70,7 +70,10 @@ class _HandlePool:
     key = torch.device(device).index
     s = self._plan_streams.get(key)
     if s is None:
-      s = torch.cuda.Stream(device=device)
+      # highest priority: the planning calls are host-synchronous (they read back a few counts), so the helper thread
+      # -- and through it the enqueueing thread -- waits for these small kernels; they must not queue behind the
+      # compute / weight-gradient streams' workgroups
+      s = torch.cuda.Stream(device=device, priority=-1)
       self._plan_streams[key] = s
     return s
 
