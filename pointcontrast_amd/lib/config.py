@@ -22,6 +22,7 @@ DEFAULTS = {
     "opt": {"optimizer": "SGD", "max_iter": 300000, "lr": 0.1, "momentum": 0.8, "weight_decay": 1e-4,
             "bn_momentum": 0.05, "exp_gamma": 0.99, "scheduler": "ExpLR"},
     "misc": {"out_dir": "./outputs", "use_gpu": True, "num_gpus": 1, "weight": None, "lenient_weight_loading": False,
+             "weight_kernel_order": "hybrid",  # "hypercube": see lib/checkpoint.py
              "train_num_thread": 2, "nceT": 0.07, "npos": 4096, "seed": 0},
     "data": {"dataset": "SyntheticScanNetPairDataset", "voxel_size": 0.025, "dataset_root_dir": None,
              "scannet_match_dir": None, "num_pairs": 64},

@@ -44,14 +44,7 @@ def _hash(arr, M):
   return hv
 
 
-def load_state(model, weights, lenient_weight_loading=False):
-  if lenient_weight_loading:
-    own = model.state_dict()
-    keep = {k: v for k, v in weights.items() if k in own and v.size() == own[k].size()}
-    logging.info("Load weights:" + ", ".join(keep.keys()))
-    own.update(keep)
-    weights = own
-  model.load_state_dict(weights, strict=True)
+from .checkpoint import load_state  # noqa: E402,F401  (pc/lib/ddp_trainer.py:54-69)
 
 
 class ContrastiveLossTrainer:
@@ -98,7 +91,8 @@ class ContrastiveLossTrainer:
 
     if config.misc.weight:
       state = torch.load(config.misc.weight, map_location="cpu", weights_only=False)
-      load_state(model, state["state_dict"], config.misc.lenient_weight_loading)
+      load_state(model, state["state_dict"], config.misc.lenient_weight_loading,
+                 kernel_order=config.misc.get("weight_kernel_order", "hybrid"))
     ckpt = "weights/weights.pth"
     if os.path.isfile(ckpt):
       state = torch.load(ckpt, map_location="cpu", weights_only=False)

@@ -888,3 +888,29 @@ def test_full_size_streamk_matches_plain(ME, full_batch, cin, cout, monkeypatch)
   monkeypatch.delenv("PCMI_SPCONV_STREAMK")
   assert_close(res["16"][0], res["0"][0], 1e-5, "stream-K forward")
   assert_close(res["16"][1], res["0"][1], 1e-5, "stream-K backward-data")
+
+
+@pytest.mark.parametrize("size,cin,cout", [("small", 64, 96), ("mid", 128, 32), ("large", 96, 96)])
+def test_conv16_matches_32row_kernel(ME, size, cin, cout, monkeypatch):
+  """The 16-row (v_mfma_f32_16x16x4_f32, per-16-row offset skipping) kernel against the 32-row kernel on the same
+  maps (PCMI_CONV16: minimum rows for the 16-row kernel; 1 = always, 0 = never): forward and backward-data."""
+  from pointcontrast_amd import functional as PF
+  C = _coords(size)
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  torch.manual_seed(4)
+  W = (torch.randn(27, cin, cout, device=DEV) / (cin * 27) ** 0.5).requires_grad_(True)
+  b = torch.randn(cout, device=DEV)
+  g = torch.randn(len(C), cout, device=DEV)
+  res = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("PCMI_CONV16", mode)
+    x = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
+    y = PF.SparseConvFunction.apply(x, W, b, m, False, len(C), cm)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res[mode] = (y.detach().clone(), x.grad.clone())
+  monkeypatch.delenv("PCMI_CONV16")
+  assert_close(res["1"][0], res["0"][0], 1e-5, "16-row forward")
+  assert_close(res["1"][1], res["0"][1], 1e-5, "16-row backward-data")

@@ -254,3 +254,32 @@ def test_scannet_match_pair_dataset_and_infinite_loader(tmp_path):
     assert (np.diff(batch["correspondences"][:, 0].numpy()) >= 0).all()
   with pytest.raises(ValueError, match="does not exist"):
     make_data_loader(get_config(["data.dataset=Nope"]), 4)
+
+
+def test_checkpoint_prefixes_and_kernel_order_switch(built_lib):
+  """lib/checkpoint.py: 'module.' / 'encoder.' prefixes are stripped (downstream/semseg/lib/utils.py:23-29); the
+  slice-order switch permutes exactly the 27-slice HYBRID kernels, by offset, and is its own inverse."""
+  from oracle import sparse_ref as sr
+  from pointcontrast_amd.lib import checkpoint as ck
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.model import load_model
+  import pointcontrast_amd.minkowski as ME
+  torch.manual_seed(0)
+  m = load_model("Res16UNet14")(3, 32, get_config([]), D=3)
+  sd = {k: v.clone() for k, v in m.state_dict().items()}
+  wrapped = {"module." + k: v for k, v in sd.items()}
+  assert set(ck.load_state_with_same_shape(m, wrapped)) == set(sd)
+  perm = ck.slice_permutation(ME.RegionType.HYPERCUBE, ME.RegionType.HYBRID)
+  cube, hyb = sr.region_offsets(3, sr.HYPERCUBE), sr.region_offsets(3, sr.HYBRID)
+  assert (cube[perm] == hyb).all() and sorted(perm.tolist()) == list(range(27))
+  names = ck.hybrid_kernel_names(m)
+  assert "block1.0.conv1.kernel" in names and "conv0p1s1.kernel" not in names and "final.kernel" not in names
+  as_file = ck.convert_kernel_order(m, sd, "hypercube", inverse=True)   # what a hypercube-ordered file would hold
+  assert not torch.equal(as_file["block1.0.conv1.kernel"], sd["block1.0.conv1.kernel"])
+  assert torch.equal(as_file["conv0p1s1.kernel"], sd["conv0p1s1.kernel"])
+  back = ck.convert_kernel_order(m, as_file, "hypercube")
+  for k in sd:
+    assert torch.equal(back[k], sd[k]), k
+  m2 = load_model("Res16UNet14")(3, 32, get_config([]), D=3)
+  ck.load_state(m2, {"module." + k: v for k, v in as_file.items()}, kernel_order="hypercube")
+  assert torch.equal(m2.state_dict()["block4.0.conv2.kernel"], sd["block4.0.conv2.kernel"])
