@@ -263,6 +263,33 @@ size_t pcmi_hardest_workspace_bytes(int64_t p);
  * flat fp32 buffer:  g = grad_scale*g + wd*w;  v = mu*v + g;  w -= lr*v.
  * (dampening 0, no Nesterov; a zero-filled v reproduces torch's first-step buffer init.)
  * ------------------------------------------------------------------------------------------ */
+/* ---- loader-side geometry on the device (csrc/loader.hip) -------------------------------------
+ * pcmi_voxelize  = ME.utils.sparse_quantize(xyz / voxel_size, return_index=True) of the dataset item
+ *   (pc/lib/ddp_data_loaders.py:228-229): first_index[0 .. *n_unique) = ascending indices of the first point of every
+ *   occupied voxel, coords (nullable, [n_unique, 3]) = floor(xyz[first_index] / voxel_size).  xyz: device fp64 [n, 3].
+ * pcmi_match_radius = get_matching_indices (pc/lib/ddp_data_loaders.py:36-49): all (i, j) with
+ *   |R src_i + t - dst_j| <= radius, rigid3x4_host = [R | t] row-major (12 host doubles); pairs [*n_pairs, 2] sorted by
+ *   (i, j).  pairs == NULL: only counts.  PCMI_ERR_WORKSPACE if pairs_capacity is too small (*n_pairs_host = needed).
+ * Both synchronise the stream (they return counts) and are bit-exact against oracle/loader_ref.py. */
+size_t pcmi_voxelize_workspace_bytes(int64_t n);
+int pcmi_voxelize(const double* xyz, int64_t n, double voxel_size, int32_t* first_index, int32_t* coords,
+                  int64_t* n_unique_host, void* ws, size_t ws_bytes, pcmi_stream_t stream);
+size_t pcmi_match_radius_workspace_bytes(int64_t n0, int64_t n1);
+int pcmi_match_radius(const double* src, int64_t n0, const double* rigid3x4_host, const double* dst, int64_t n1,
+                      double radius, int32_t* pairs, int64_t pairs_capacity, int64_t* n_pairs_host, void* ws,
+                      size_t ws_bytes, pcmi_stream_t stream);
+
+/* Softmax cross-entropy over the rows of logits [n, c] with an ignore label -- the loss of the downstream semantic
+ * segmentation fine-tuning that reuses this backbone with out_channels = number of classes
+ * (downstream/semseg/lib/train.py:64,124: nn.CrossEntropyLoss(ignore_index=config.ignore_label)).
+ * out2[0] = mean loss over the counted rows, out2[1] = their number (device).  _bwd: dlogits = gloss[0] * dloss/dlogits. */
+size_t pcmi_softmax_ce_workspace_bytes(int64_t n);
+int pcmi_softmax_ce_fwd(const float* logits, int64_t ld, int64_t n, int c, const int32_t* labels,
+                        int ignore_label, float* out2, void* ws, size_t ws_bytes, pcmi_stream_t stream);
+int pcmi_softmax_ce_bwd(const float* logits, int64_t ld, int64_t n, int c, const int32_t* labels,
+                        int ignore_label, const float* out2, const float* gloss, float* dlogits,
+                        int64_t d_ld, pcmi_stream_t stream);
+
 int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum,
                   float weight_decay, float grad_scale, pcmi_stream_t stream);
 

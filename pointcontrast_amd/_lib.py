@@ -107,6 +107,14 @@ PROTOTYPES = {
                                         c_vp, c_sz, c_vp]),
     "pcmi_hardest_loss_bwd": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, C.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pcmi_voxelize_workspace_bytes": (c_sz, [c_i64]),
+    "pcmi_voxelize": (C.c_int, [c_vp, c_i64, C.c_double, c_vp, c_vp, C.POINTER(c_i64), c_vp, c_sz, c_vp]),
+    "pcmi_match_radius_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "pcmi_match_radius": (C.c_int, [c_vp, c_i64, C.POINTER(C.c_double), c_vp, c_i64, C.c_double, c_vp, c_i64,
+                                    C.POINTER(c_i64), c_vp, c_sz, c_vp]),
+    "pcmi_softmax_ce_workspace_bytes": (c_sz, [c_i64]),
+    "pcmi_softmax_ce_fwd": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, C.c_int, c_vp, c_vp, c_sz, c_vp]),
+    "pcmi_softmax_ce_bwd": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, C.c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pcmi_sgd_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "pcmi_net_create": (C.c_int, [C.POINTER(NetTensor), C.c_int, C.POINTER(NetOp), C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(c_vp)]),

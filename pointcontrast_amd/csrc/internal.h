@@ -13,6 +13,19 @@ int spconv_backward_data(const float* gout, int64_t gout_ld, int64_t n_out, int 
 int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
                            int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
                            float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// the same three on the MFMA path proper (channel counts multiples of 32, or the 3-channel stem); the entry points
+// above add zero-padded staging for any other width (widths.hip)
+int spconv_forward_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
+                       const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
+                       int64_t n_out, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int spconv_backward_data_m32(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
+                             const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
+                             int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                               int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
+                               float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+size_t spconv_workspace_m32(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M);
+
 int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
                 int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
                 int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,

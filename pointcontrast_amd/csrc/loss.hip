@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "internal.h"
 
 namespace pcmi {
 
@@ -430,6 +431,74 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t s
   atomicAdd(dst + idx[r] * dst_ld + col, src[r * src_ld + col]);
 }
 
+// ---- softmax cross-entropy with ignore label (downstream reuse of the backbone) ---------------------------------
+// loss = mean over the rows whose label != ignore of (logsumexp(x_r) - x_r[label_r]) -- torch.nn.CrossEntropyLoss(
+// ignore_index=...) as used by downstream/semseg/lib/train.py:64,124.  One thread per row (c is the number of classes:
+// a wave reads 64 consecutive rows, i.e. one contiguous run); per-block (sum, count) partials, finished by the
+// last-arriving workgroup in block order (deterministic).  out[0] = loss, out[1] = number of counted rows.
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int c,
+                                                     const int32_t* __restrict__ label, int ignore,
+                                                     float* __restrict__ part, unsigned* counter, float* __restrict__ out) {
+  __shared__ float s_red[4][2];
+  __shared__ unsigned s_last;
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float v[2] = {0.f, 0.f};
+  if (r < n) {
+    const int32_t lb = label[r];
+    if (lb != ignore && lb >= 0 && lb < c) {
+      const float* xr = x + r * ld;
+      float m = -INFINITY;
+      for (int j = 0; j < c; ++j) m = fmaxf(m, xr[j]);
+      float se = 0.f;
+      for (int j = 0; j < c; ++j) se += __expf(xr[j] - m);
+      v[0] = m + __logf(se) - xr[lb];
+      v[1] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v[q] += __shfl_xor(v[q], d, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = v[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[(int64_t)blockIdx.x * 2 + threadIdx.x] =
+        s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+  if (!arrive_last(counter, gridDim.x, &s_last)) return;
+  if (threadIdx.x == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (unsigned b = 0; b < gridDim.x; ++b) {
+      s0 += part[2 * b];
+      s1 += part[2 * b + 1];
+    }
+    out[0] = s1 > 0.f ? s0 / s1 : 0.f;
+    out[1] = s1;
+  }
+}
+
+// dx[r][j] = gloss / count * (softmax(x_r)[j] - [j == label_r])  (zero rows for ignored labels)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int c,
+                                                     const int32_t* __restrict__ label, int ignore,
+                                                     const float* __restrict__ stats, const float* __restrict__ gloss,
+                                                     float* __restrict__ dx, int64_t dx_ld) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const int32_t lb = label[r];
+  float* dr = dx + r * dx_ld;
+  if (lb == ignore || lb < 0 || lb >= c || stats[1] <= 0.f) {
+    for (int j = 0; j < c; ++j) dr[j] = 0.f;
+    return;
+  }
+  const float* xr = x + r * ld;
+  float m = -INFINITY;
+  for (int j = 0; j < c; ++j) m = fmaxf(m, xr[j]);
+  float se = 0.f;
+  for (int j = 0; j < c; ++j) se += __expf(xr[j] - m);
+  const float scale = gloss[0] / stats[1], inv = 1.f / se;
+  for (int j = 0; j < c; ++j) dr[j] = scale * (__expf(xr[j] - m) * inv - (j == lb ? 1.f : 0.f));
+}
+
 // ---- SGD ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
                                                   int64_t n, float lr, float mu, float wd, float gscale) {
@@ -604,6 +673,30 @@ int pcmi_hardest_loss_bwd(const float* posF0, const float* posF1, int64_t p, con
   hardest_grad_kernel<<<dim3((unsigned)ceil_div(p * c, 256)), 256, 0, as_stream(stream)>>>(
       posF0, posF1, p, c, subF0, subF1, d01min, d01ind, mask0, d10min, d10ind, mask1, pos_thresh, neg_thresh, stats, gl,
       dposF0, dposF1, dsubF0, dsubF1);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+size_t pcmi_softmax_ce_workspace_bytes(int64_t n) { return (size_t)ceil_div(std::max<int64_t>(n, 1), 256) * 2 * sizeof(float) + 256; }
+
+int pcmi_softmax_ce_fwd(const float* logits, int64_t ld, int64_t n, int c, const int32_t* labels, int ignore_label,
+                        float* out2, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
+  PCMI_REQUIRE(logits && labels && out2 && n > 0 && c > 0 && ld >= c, PCMI_ERR_INVALID, "softmax_ce_fwd: bad argument");
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_softmax_ce_workspace_bytes(n), PCMI_ERR_WORKSPACE, "softmax_ce_fwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  unsigned* counter = stream_counters(st, 1);
+  if (!counter) return PCMI_ERR_HIP;
+  ce_fwd_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, st>>>(logits, ld, n, c, labels, ignore_label, (float*)ws, counter, out2);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int pcmi_softmax_ce_bwd(const float* logits, int64_t ld, int64_t n, int c, const int32_t* labels, int ignore_label,
+                        const float* out2, const float* gloss, float* dlogits, int64_t d_ld, pcmi_stream_t stream) {
+  PCMI_REQUIRE(logits && labels && out2 && gloss && dlogits && n > 0 && c > 0 && ld >= c && d_ld >= c, PCMI_ERR_INVALID,
+               "softmax_ce_bwd: bad argument");
+  ce_bwd_kernel<<<(unsigned)ceil_div(n, 256), 256, 0, as_stream(stream)>>>(logits, ld, n, c, labels, ignore_label, out2, gloss,
+                                                                           dlogits, d_ld);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

@@ -1049,9 +1049,9 @@ size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, 
 
 namespace pcmi {
 
-int spconv_forward(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
-                   const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
-                   int64_t n_out, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+int spconv_forward_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* weight, int cout,
+                       const pcmi_kmap_t* map, int transpose, const float* bias, float* out, int64_t out_ld,
+                       int64_t n_out, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   PCMI_REQUIRE(in && weight && out && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_fwd: null/empty argument");
   if (map) {
     const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
@@ -1078,9 +1078,9 @@ int spconv_forward(const float* in, int64_t in_ld, int64_t n_in, int cin, const 
                       out_ld, n_out, accumulate, ws, ws_bytes, st);
 }
 
-int spconv_backward_data(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
-                         const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
-                         int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+int spconv_backward_data_m32(const float* gout, int64_t gout_ld, int64_t n_out, int cout, const float* weight, int cin,
+                             const pcmi_kmap_t* map, int transpose, float* gin, int64_t gin_ld, int64_t n_in,
+                             int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   PCMI_REQUIRE(gout && weight && gin && cin >= 8 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_data: bad argument (cin=%d)", cin);
   if (!map) {
     PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_data: dense path needs n_in == n_out");

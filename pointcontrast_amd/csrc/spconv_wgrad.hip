@@ -525,19 +525,17 @@ namespace pcmi {
 size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K);
 }
 
-extern "C" {
-
-size_t pcmi_spconv_workspace_bytes(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M) {
+namespace pcmi {
+size_t spconv_workspace_m32(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M) {
   return std::max(spconv_fwd_bwd_workspace(n_in, n_out, cin, cout, K),
                   spconv_wgrad_workspace(n_in, n_out, cin, cout, K, M)) + 256;
 }
-
-}  // extern "C"
+}  // namespace pcmi
 
 namespace pcmi {
-int spconv_backward_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
-                           int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
-                           float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                               int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
+                               float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   PCMI_REQUIRE(in && gout && gweight && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_weight: bad argument");
   const int K = map ? map->K : 1;
   int64_t M;

@@ -314,6 +314,35 @@ class HardestLossFunction(Function):
     return (g0, g1, gs0, gs1) + (None,) * 8
 
 
+class SoftmaxCrossEntropyFunction(Function):
+  """torch.nn.CrossEntropyLoss(ignore_index=ignore_label) on logits [n, c] / int labels [n]
+  (downstream/semseg/lib/train.py:64,124), as libpcmi kernels."""
+
+  @staticmethod
+  def forward(ctx, logits, labels, ignore_label):
+    require_cuda(logits, "softmax cross-entropy")
+    x = logits if (logits.stride(1) == 1 and logits.dtype == torch.float32) else logits.float().contiguous()
+    lb = labels.to(device=x.device, dtype=torch.int32).contiguous()
+    n, c = x.shape
+    out2 = torch.empty(2, dtype=torch.float32, device=x.device)
+    ws, wsb = ws_args(lib.pcmi_softmax_ce_workspace_bytes(n), x.device)
+    check(lib.pcmi_softmax_ce_fwd(ptr(x), x.stride(0), n, c, ptr(lb), int(ignore_label), ptr(out2), ws, wsb, cur_stream(x.device)))
+    ctx.save_for_backward(x, lb, out2)
+    ctx.ignore = int(ignore_label)
+    return out2[0]
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, gloss):
+    x, lb, out2 = ctx.saved_tensors
+    n, c = x.shape
+    dx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    g = gloss.reshape(1).to(dtype=torch.float32, device=x.device).contiguous()
+    check(lib.pcmi_softmax_ce_bwd(ptr(x), x.stride(0), n, c, ptr(lb), ctx.ignore, ptr(out2), ptr(g), ptr(dx), c,
+                                  cur_stream(x.device)))
+    return dx, None, None
+
+
 def sgd_step(w, g, v, lr, momentum, weight_decay, grad_scale=1.0):
   """torch.optim.SGD.step on flat buffers (pc/lib/ddp_trainer.py:107-111,319,435)."""
   require_cuda(w, "sgd step")

@@ -25,14 +25,26 @@ from .data_sampler import DistributedInfSampler, InfSampler
 def get_matching_indices(xyz0, xyz1, trans, search_radius, K=None):
   """All (i, j) with |trans(xyz0[i]) - xyz1[j]| <= radius, ordered by i (pc/lib/ddp_data_loaders.py:36-49; the
   reference walks an open3d KD-tree point by point -- here one batched cKDTree query)."""
-  src = xyz0 @ trans[:3, :3].T + trans[:3, 3]
-  nb = cKDTree(xyz1).query_ball_point(src, search_radius)
+  src = _apply_rigid(trans, xyz0)
+  nb = cKDTree(xyz1).query_ball_point(src, search_radius * (1 + 1e-9))  # candidates; the exact test follows
   if K is not None:
     nb = [x[:K] for x in nb]
   cnt = np.fromiter((len(x) for x in nb), np.int64, len(nb))
   ii = np.repeat(np.arange(len(nb)), cnt)
   jj = np.concatenate([np.sort(np.asarray(x, np.int64)) for x in nb]) if cnt.sum() else np.zeros(0, np.int64)
-  return np.stack([ii, jj], 1)
+  # membership decided by the same separately-rounded float64 expression the device kernel evaluates
+  ex, ey, ez = src[ii, 0] - xyz1[jj, 0], src[ii, 1] - xyz1[jj, 1], src[ii, 2] - xyz1[jj, 2]
+  keep = ((ex * ex + ey * ey) + ez * ez) <= np.float64(search_radius) * np.float64(search_radius)
+  return np.stack([ii[keep], jj[keep]], 1)
+
+
+def _apply_rigid(trans, xyz):
+  """((R0 x + R1 y) + R2 z) + t, each operation rounded on its own (what csrc/loader.hip computes)."""
+  T, p = np.asarray(trans, dtype=np.float64), np.asarray(xyz, dtype=np.float64)
+  out = np.empty_like(p)
+  for r in range(3):
+    out[:, r] = ((T[r, 0] * p[:, 0] + T[r, 1] * p[:, 1]) + T[r, 2] * p[:, 2]) + T[r, 3]
+  return out
 
 
 class ScanNetMatchPairDataset(torch.utils.data.Dataset):
@@ -50,6 +62,10 @@ class ScanNetMatchPairDataset(torch.utils.data.Dataset):
     self.randg = np.random.RandomState()
     if manual_seed:
       self.reset_seed()
+    # data.device_geometry: voxelisation + correspondence search as libpcmi kernels (lib/device_loader.py) instead of
+    # numpy / cKDTree on the host; identical results (both bit-exact against oracle/loader_ref.py).  The item is then
+    # produced by the process that owns the GPU: use misc.train_num_thread=0.
+    self.device_geometry = bool(config.data.get("device_geometry", False))
     self.root = config.data.dataset_root_dir
     if not self.root or not config.data.scannet_match_dir:
       raise ValueError("ScanNetMatchPairDataset needs data.dataset_root_dir and data.scannet_match_dir (the pair list)")
@@ -81,9 +97,15 @@ class ScanNetMatchPairDataset(torch.utils.data.Dataset):
       xyz1 = xyz1 @ T1[:3, :3].T + T1[:3, 3]
     else:
       trans = np.identity(4)
-    xyz0 = xyz0[ME.utils.sparse_quantize(xyz0 / self.voxel_size, return_index=True)]
-    xyz1 = xyz1[ME.utils.sparse_quantize(xyz1 / self.voxel_size, return_index=True)]
-    matches = get_matching_indices(xyz0, xyz1, trans, radius)
+    if self.device_geometry:
+      from . import device_loader as dl
+      xyz0 = xyz0[dl.sparse_quantize_index(xyz0, self.voxel_size)]
+      xyz1 = xyz1[dl.sparse_quantize_index(xyz1, self.voxel_size)]
+      matches = dl.get_matching_indices(xyz0, xyz1, trans, radius)
+    else:
+      xyz0 = xyz0[ME.utils.sparse_quantize(xyz0 / self.voxel_size, return_index=True)]
+      xyz1 = xyz1[ME.utils.sparse_quantize(xyz1 / self.voxel_size, return_index=True)]
+      matches = get_matching_indices(xyz0, xyz1, trans, radius)
     feats0, feats1 = np.ones((len(xyz0), 3)), np.ones((len(xyz1), 3))
     coords0, coords1 = np.floor(xyz0 / self.voxel_size), np.floor(xyz1 / self.voxel_size)
     if self.transform:

@@ -1,0 +1,90 @@
+"""Row N3 (first slice): the backbone reused downstream with out_channels = number of classes
+(downstream/semseg/models/res16unet.py:202-260: 1x1 head of width num_labels, no feature normalisation) and the
+semantic-segmentation loss (downstream/semseg/lib/train.py:64,124: CrossEntropyLoss(ignore_index)).  Needs
+convolutions of ANY width (csrc/widths.hip stages zero-padded operands for the 32-channel matrix-core kernels)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import DEV, assert_close, _conv_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ME():
+  import pointcontrast_amd.minkowski as me
+  return me
+
+
+@pytest.mark.parametrize("size,kind,cin,cout", [("small", "1x1", 96, 20), ("small", "k3_hybrid", 48, 20), ("small", "down", 40, 72),
+                                                ("small", "up", 72, 40), ("tiny", "k3_cube", 16, 16), ("mid", "1x1", 96, 13),
+                                                ("mid", "k3_hybrid", 32, 20)])
+def test_spconv_any_width(ME, size, kind, cin, cout):
+  res = _conv_case(ME, size, kind, cin, cout, bias=(kind == "1x1"))
+  for name, (got, ref) in res.items():
+    assert_close(got, ref, 1e-4, "%s %s %d->%d %s" % (size, kind, cin, cout, name))
+
+
+@pytest.mark.parametrize("n,c", [(1000, 20), (70000, 20), (333, 13), (5000, 41)])
+def test_softmax_cross_entropy_with_ignore_label(n, c):
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(n)
+  x = torch.randn(n, c) * 3
+  lb = torch.randint(0, c, (n,))
+  lb[torch.rand(n) < 0.2] = 255
+  xr = x.clone().requires_grad_(True)
+  lref = torch.nn.functional.cross_entropy(xr, lb, ignore_index=255)
+  (lref * 1.3).backward()
+  xd = x.to(DEV).requires_grad_(True)
+  ld = PF.SoftmaxCrossEntropyFunction.apply(xd, lb.to(DEV), 255)
+  (ld * 1.3).backward()
+  assert abs(float(ld) - float(lref)) <= 1e-5 * abs(float(lref))
+  assert_close(xd.grad, xr.grad, 1e-5, "dlogits")
+  all_ignored = PF.SoftmaxCrossEntropyFunction.apply(x.to(DEV), torch.full((n,), 255), 255)
+  assert float(all_ignored) == 0.0
+
+
+@pytest.mark.parametrize("engine", ["autograd", "native"])
+def test_segmentation_head_forward_loss_and_head_gradients(ME, engine):
+  """Res16UNet14 with a 20-class head and normalize_feature=False: logits, CE loss (ignore 255) and the gradients of
+  the head against the oracle, through the per-layer path and through the native executor."""
+  from oracle import model_ref as mr, sparse_ref as sr
+  from pointcontrast_amd import functional as PF
+  from pointcontrast_amd.engine import NativeEngine
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.distributed import FlatParameters
+  from pointcontrast_amd.model import load_model
+  cfg = get_config(["net.normalize_feature=False"])
+  torch.manual_seed(0)
+  ref = mr.MODELS["Res16UNet14"](3, 20, bn_momentum=cfg.opt.bn_momentum, normalize_feature=False)
+  dev = load_model("Res16UNet14")(3, 20, cfg, D=3)
+  dev.load_state_dict(ref.state_dict())
+  dev = dev.to(DEV).train()
+  ref.train()
+  b = synthetic.make_batch(seed=3, batch_size=1, crop=0.6)
+  C, F = b["sinput0_C"], torch.from_numpy(b["sinput0_F"])
+  labels = torch.from_numpy(np.random.RandomState(0).randint(0, 20, len(C)))
+  labels[::7] = 255
+  yr = ref(sr.SparseTensorRef(F, coords=C)).F
+  lref = torch.nn.functional.cross_entropy(yr, labels, ignore_index=255)
+  lref.backward()
+  st = ME.SparseTensor(F, coords=torch.from_numpy(C)).to(DEV)
+  if engine == "native":
+    flat = FlatParameters(dev.parameters())
+    eng = NativeEngine(dev, flat)
+    yd = eng.forward(0, st).requires_grad_(True)
+  else:
+    yd = dev(st).F
+  assert yd.shape == (len(C), 20)
+  assert_close(yd, yr, 1e-4, "segmentation logits (%s)" % engine)
+  ld = PF.SoftmaxCrossEntropyFunction.apply(yd, labels.to(DEV), 255)
+  assert abs(float(ld) - float(lref)) <= 1e-4 * abs(float(lref))
+  ld.backward()
+  if engine == "native":
+    flat.zero_grad()
+    eng.backward(0, yd.grad)
+  assert_close(dev.final.kernel.grad, ref.final.kernel.grad, 1e-4, "head kernel gradient")
+  assert_close(dev.final.bias.grad, ref.final.bias.grad, 1e-4, "head bias gradient")
+  assert_close(dev.block8[0].norm2.bn.bias.grad, ref.block8[0].norm2.bn.bias.grad, 2e-3, "a gradient upstream of the head")
