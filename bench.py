@@ -266,7 +266,8 @@ def main():
   from pointcontrast_amd.lib.timer import AverageMeter, Timer
   cfg = get_config(["net.model=%s" % args.model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1",
                     "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world),
-                    "misc.engine=%s" % args.engine, "misc.host_profile=True"] + list(args.set))
+                    "misc.engine=%s" % args.engine, "misc.host_profile=True",
+                    "misc.reducer_profile=%s" % (world > 1)] + list(args.set))
   batch = get_batch(seed=rank, batch_size=args.batch, voxel_size=args.voxel)
   loader = FixedBatchLoader([batch], batch_size=args.batch)
   torch.manual_seed(0)
@@ -322,7 +323,13 @@ def main():
                    **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),
                    **({"host_phase_ms_per_step": {k: round(v / (args.steps + args.warmup), 3) for k, v in trainer.host_ms.items()}}
                       if trainer.host_ms else {}),
-                   "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3)},
+                   "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3),
+                   # N > 1: what RCCL saw -- ranks, backend, gradient buckets, and how much of the all-reduce was hidden
+                   "collective": ({"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                   "allreduce_mb_per_step": round(trainer.flat.numel * 4 / 2 ** 20, 1),
+                                   "buckets": len(trainer.reducer.buckets),
+                                   "overlap": trainer.reducer.overlap_report(skip_steps=args.warmup)}
+                                  if world > 1 else None)},
     }
     if args.layer_table:
       with open(args.layer_table, "w") as f:

@@ -71,35 +71,36 @@ struct ConvArgs {
   float* sk_part;           // [gridDim.x][2][128][N] partial tiles
 };
 
-// Weight chunk [32 x 32*NT] global -> registers -> LDS.  WT: B[c][n] = W[n][c] (backward-data).
-template <int NT, bool WT>
-__device__ __forceinline__ void load_b_regs(v4f (&breg)[NT], const float* __restrict__ wb, int64_t w_sc,
+// Weight chunk [KC x 32*NT] global -> registers -> LDS (NT * KC / 32 float4 per thread).  WT: B[c][n] = W[n][c]
+// (backward-data).
+template <int NT, bool WT, int KC = kKC>
+__device__ __forceinline__ void load_b_regs(v4f (&breg)[NT * KC / 32], const float* __restrict__ wb, int64_t w_sc,
                                             int64_t w_sn, int c0, int n0, int t) {
   constexpr int NS = 32 * NT;
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
+  for (int i = 0; i < NT * KC / 32; ++i) {
     const int e = t + i * 256;  // float4 index inside the chunk
     if (!WT) {
       const int c = e / (NS / 4), n4 = e % (NS / 4);
       breg[i] = *reinterpret_cast<const v4f*>(wb + (int64_t)(c0 + c) * w_sc + n0 + n4 * 4);
     } else {
-      const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+      const int n = e / (KC / 4), c4 = e % (KC / 4);
       breg[i] = *reinterpret_cast<const v4f*>(wb + (int64_t)(n0 + n) * w_sn + c0 + c4 * 4);
     }
   }
 }
 
-template <int NT, bool WT, int LDB>
-__device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT], float* __restrict__ sb, int t) {
+template <int NT, bool WT, int LDB, int KC = kKC>
+__device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT * KC / 32], float* __restrict__ sb, int t) {
   constexpr int NS = 32 * NT;
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
+  for (int i = 0; i < NT * KC / 32; ++i) {
     const int e = t + i * 256;
     if (!WT) {
       const int c = e / (NS / 4), n4 = e % (NS / 4);
       *reinterpret_cast<v4f*>(sb + c * LDB + n4 * 4) = breg[i];
     } else {
-      const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+      const int n = e / (KC / 4), c4 = e % (KC / 4);
       sb[(c4 * 4 + 0) * LDB + n] = breg[i].x;
       sb[(c4 * 4 + 1) * LDB + n] = breg[i].y;
       sb[(c4 * 4 + 2) * LDB + n] = breg[i].z;
@@ -115,17 +116,22 @@ __device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT], float* __res
 // takes units [g*per, (g+1)*per): whole tiles are written as usual, the at most two tiles a workgroup shares
 // with its neighbours go to partial slots [g][0 = its first piece | 1 = its last piece] and
 // sk_fixup_kernel adds the pieces of a split tile in workgroup order (deterministic).
-template <int NT, int RW, bool WT, bool PAIR, bool SK = false>
+// KC: contraction channels per staged chunk (= per barrier).  32 everywhere except the narrow-slice launches of the
+// small levels (NT = 1 with KC = 128, NT = 2 with KC = 64): there a 32-channel step is 16 MFMAs per wave -- 0.4 us,
+// shorter than the L2 latency of the next step's gathers and weights, so the kernel ran at one memory latency per
+// step (27 steps x ~0.9 us for a 256-channel conv over 1.3k rows); a deeper chunk gives every barrier 4x the matrix
+// work and 4x the loads in flight.  Those variants trade the third wave per SIMD for the larger operand rings.
+template <int NT, int RW, bool WT, bool PAIR, bool SK = false, int KC = kKC>
 // min 3 waves/SIMD: with this bound hipcc keeps the accumulators in plain VGPRs (<= 158 in total, no scratch);
 // without it it split them into AGPRs at 170-220 registers total and 2 waves/SIMD
-__global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvArgs a) {
   constexpr int TM = 32 * RW;        // rows per workgroup tile
   constexpr int KG = 4 / RW;         // wave groups splitting the contraction blocks
-  constexpr int BPG = 4 / KG;        // eight-channel blocks per wave group per chunk
+  constexpr int BPG = KC / 8 / KG;   // eight-channel blocks per wave group per chunk
   constexpr int NS = 32 * NT;        // output-channel slice of this workgroup
   constexpr int LDB = WT ? NS + 1 : NS;
   constexpr int KSLOTS = PAIR ? 1 : PCMI_MAX_KERNEL_VOLUME;
-  constexpr int STAGE_FLOATS = 2 * kKC * LDB;
+  constexpr int STAGE_FLOATS = 2 * KC * LDB;
   constexpr int RED_FLOATS = (KG > 1) ? (KG - 1) * RW * 32 * NS : 0;
   constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
 
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   }
   __syncthreads();
   const int nk = s_nk;
-  const int nch = a.C / kKC;
+  const int nch = a.C / KC;
   const int nsteps = nk * nch;
   const int kbeg_blk = PAIR ? 0 : (int)((int64_t)a.K * blockIdx.z / a.ksplit);
 
@@ -277,16 +283,16 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   // ---- staging helpers -------------------------------------------------------------------
-  // (kKC * NS / 4 = 256 * NT float4 per chunk -> exactly NT per thread; kept in registers: the loops
+  // (KC * NS / 4 float4 per chunk -> NT * KC / 32 per thread; kept in registers: the loops
   //  below are fully unrolled over a by-reference array, a lambda capture of it went to scratch)
-  v4f breg[NT];
+  v4f breg[NT * KC / 32];
   auto load_b = [&](int step) {
     const int kslot = s_klist[step / nch];
-    const int c0 = (step % nch) * kKC;
+    const int c0 = (step % nch) * KC;
     const int wk = PAIR ? a.wsel[k_single] : (SK ? a.wsel[s_kabs[kslot]] : a.wsel[kbeg_blk + kslot]);
-    load_b_regs<NT, WT>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
+    load_b_regs<NT, WT, KC>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
   };
-  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
+  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB, KC>(breg, s_f + buf * (KC * LDB), t); };
   // A operands (gathers: the long-latency loads) and B chunks (weights: L2 hits shared by every workgroup, through
   // LDS) are both fetched one 32-channel step ahead.  (A two-steps-ahead register ring was measured: no gain once
   // the accumulators stayed in VGPRs, and one wave per SIMD less.)
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
   bool v0 = false, v1 = false;
   auto load_a = [&](int step, float4* dst) -> bool {
     const int kslot = s_klist[step / nch];
-    const int c0 = (step % nch) * kKC;
+    const int c0 = (step % nch) * KC;
     const int32_t idx = s_idx[kslot][rg * 32 + r];
     if (idx >= 0) {
       const float* xp = a.x + (int64_t)idx * a.x_ld + c0 + 4 * h;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256, 3) void spconv_mfma_kernel(ConvArgs a) {
         // Written inline, hipcc emitted ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, i.e. the full LDS latency in
         // front of every 128 cycles of matrix work: SQ_VALU_MFMA_BUSY_CYCLES showed the pipe 52 % busy.  The
         // sched_barriers pin the order (the scheduler otherwise sinks every read next to its use again).
-        const float* sb = s_f + (step & 1) * (kKC * LDB) + r + (8 * (kg * BPG) + 4 * h) * LDB;
+        const float* sb = s_f + (step & 1) * (KC * LDB) + r + (8 * (kg * BPG) + 4 * h) * LDB;
         constexpr int QN = 4 * BPG;                                // contraction steps of this wave per chunk
         constexpr int PF0 = NT >= 3 ? 3 : (NT == 2 ? 4 : 6);       // >= ~380 cycles (6 MFMAs) between read and use
         constexpr int PF = PF0 < QN ? PF0 : QN;
@@ -859,6 +865,33 @@ static int launch16(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   return PCMI_OK;
 }
 
+// PCMI_DEEP_CHUNK: deepest chunk of the narrow-slice launches: 64 (default; NT = 1 keeps 4 waves per SIMD, NT = 2 keeps
+// 3), 128 (NT = 1 only: 194 VGPRs, 2 waves per SIMD), 0 / 32 = 32-channel chunks everywhere (A/B)
+static int deep_chunk_max() {
+  const char* e = getenv("PCMI_DEEP_CHUNK");
+  return e ? atoi(e) : 64;
+}
+
+// 128-row tiles, narrow slices: KC = 128 / 64 (NT = 1), 64 (NT = 2) when the contraction size allows; false = not taken
+template <bool WT>
+static bool launch_deep(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  const int kc_max = deep_chunk_max();
+  if (kc_max < 64) return false;
+  if (NT == 1 && a.C % 128 == 0 && kc_max >= 128) {
+    spconv_mfma_kernel<1, 4, WT, false, false, 128><<<grid, 256, 0, st>>>(a);
+    return true;
+  }
+  if (NT == 1 && a.C % 64 == 0) {
+    spconv_mfma_kernel<1, 4, WT, false, false, 64><<<grid, 256, 0, st>>>(a);
+    return true;
+  }
+  if (NT == 2 && a.C % 64 == 0) {
+    spconv_mfma_kernel<2, 4, WT, false, false, 64><<<grid, 256, 0, st>>>(a);
+    return true;
+  }
+  return false;
+}
+
 template <int RW, bool WT, bool PAIR>
 static int launch_nt(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   switch (NT) {
@@ -1025,9 +1058,12 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   }
   dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
   int rc;
-  if (p.RW == 4 && conv16_enabled(n_rows))
+  if (p.RW == 4 && conv16_enabled(n_rows)) {
     rc = w_transposed ? launch16<true, false>(p.NT, a, grid, st) : launch16<false, false>(p.NT, a, grid, st);
-  else
+  } else if (p.RW == 4 && (w_transposed ? launch_deep<true>(p.NT, a, grid, st) : launch_deep<false>(p.NT, a, grid, st))) {
+    rc = PCMI_OK;
+    PCMI_LAUNCH_CHECK();
+  } else
     rc = w_transposed ? launch_rw<true, false>(p.RW, p.NT, a, grid, st) : launch_rw<false, false>(p.RW, p.NT, a, grid, st);
   if (rc) return rc;
   if (p.ksplit > 1) {

@@ -70,7 +70,8 @@ class ContrastiveLossTrainer:
     self.model = model
     self.flat = du.FlatParameters(model.parameters())
     self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", 32.0),
-                                   force=config.misc.get("force_reducer", False))
+                                   force=config.misc.get("force_reducer", False),
+                                   profile=config.misc.get("reducer_profile", False))
     # misc.engine: "native" = whole forward / backward as one libpcmi call each (engine.py);
     #              "autograd" = per-layer torch.autograd.Function path (same kernels)
     self.engine = None

@@ -13,7 +13,7 @@ from ..runtime import ptr, cur_stream, ws_args
 
 
 def _dev(device):
-  return torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+  return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 def sparse_quantize_index(xyz, voxel_size, device=None, return_coords=False):

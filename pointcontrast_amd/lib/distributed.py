@@ -91,8 +91,11 @@ class FlatParameters:
 class GradReducer:
   """Bucketed all-reduce(SUM) of FlatParameters.g overlapped with backward."""
 
-  def __init__(self, flat, bucket_mb=32.0, process_group=None, force=False):
+  def __init__(self, flat, bucket_mb=32.0, process_group=None, force=False, profile=False):
     self.flat, self.pg = flat, process_group
+    # profile: per-bucket events (ready on the compute stream, done on the comm stream) + end of backward, so that a
+    # scaling run can report how much of the all-reduce was hidden behind backward (overlap_report)
+    self.profile, self._prof = profile, []
     self.world = get_world_size()
     # force: run the bucketed all-reduce even in a 1-rank group (exercises the RCCL / side-stream path)
     self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
@@ -138,11 +141,15 @@ class GradReducer:
     lo, hi, _ = self.buckets[b]
     chunk = self.flat.g[lo:hi]
     if self.cuda:
-      ev = torch.cuda.Event()
+      ev = torch.cuda.Event(enable_timing=self.profile)
       ev.record(torch.cuda.current_stream(chunk.device))
       self.comm_stream.wait_event(ev)
       with torch.cuda.stream(self.comm_stream):
         self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+        if self.profile:
+          done = torch.cuda.Event(enable_timing=True)
+          done.record(self.comm_stream)
+          self._prof.append(("bucket", b, (hi - lo) * 4, ev, done))
     else:
       self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
 
@@ -152,6 +159,10 @@ class GradReducer:
       return
     for b in range(len(self.buckets)):  # buckets whose parameters received no gradient this step
       self._launch(b)
+    if self.profile and self.cuda:
+      end = torch.cuda.Event(enable_timing=True)
+      end.record(torch.cuda.current_stream(self.flat.g.device))  # backward is fully enqueued up to here
+      self._prof.append(("backward_end", end))
     for w in self._works:
       w.wait()
     if self.cuda:
@@ -159,6 +170,31 @@ class GradReducer:
     self._works = []
     self._pending = [0] * len(self.buckets)
     self._launched = [False] * len(self.buckets)
+
+  def overlap_report(self, skip_steps=0):
+    """After a synchronize: per bucket the mean ready -> all-reduced time, and the mean time the all-reduce of a step
+    finished AFTER backward had finished (= communication not hidden behind backward), in ms."""
+    steps, cur = [], []
+    for rec in self._prof:
+      cur.append(rec)
+      if rec[0] == "backward_end":
+        steps.append(cur)
+        cur = []
+    steps = steps[skip_steps:]
+    if not steps:
+      return None
+    per_bucket, exposed = {}, []
+    for st in steps:
+      end = st[-1][1]
+      tail = 0.0
+      for rec in st[:-1]:
+        _, b, nbytes, ready, done = rec
+        per_bucket.setdefault(b, []).append((ready.elapsed_time(done), nbytes))
+        tail = max(tail, end.elapsed_time(done))
+      exposed.append(max(tail, 0.0))
+    return {"buckets": [{"bucket": b, "mb": round(v[0][1] / 2 ** 20, 1), "ready_to_done_ms": round(sum(x[0] for x in v) / len(v), 3)}
+                        for b, v in sorted(per_bucket.items())],
+            "exposed_after_backward_ms": round(sum(exposed) / len(exposed), 3), "steps": len(steps)}
 
   @property
   def grad_scale(self):

@@ -41,17 +41,19 @@ class Res16UNetBase(ResNetBase):
     self.inplanes = self.INIT_DIM
     self.conv0p1s1 = conv(in_channels, self.inplanes, kernel_size=config.net.conv1_kernel_size, stride=1, dilation=1, **nb)
     self.bn0 = get_norm(self.NORM_TYPE, self.inplanes, D, bn_momentum=mom)
-    skip_planes = [self.INIT_DIM]
     for i, (cname, bname, blk) in enumerate(self.ENCODER):
       setattr(self, cname, conv(self.inplanes, self.inplanes, kernel_size=2, stride=2, dilation=1, **nb))
       setattr(self, bname, get_norm(self.NORM_TYPE, self.inplanes, D, bn_momentum=mom))
       setattr(self, blk, stage(i))
-      skip_planes.append(self.inplanes)
+    # width of the skip tensor concatenated in decoder stage i (pc/model/res16unet.py:143,163,183,203): the outputs of
+    # block3 / block2 / block1 (PLANES[k] * expansion) and of the stem (INIT_DIM, no block -> no expansion)
+    skip = [self.PLANES[2] * self.BLOCK.expansion, self.PLANES[1] * self.BLOCK.expansion,
+            self.PLANES[0] * self.BLOCK.expansion, self.INIT_DIM]
     for i, (cname, bname, blk) in enumerate(self.DECODER):
       up = self.PLANES[4 + i]
       setattr(self, cname, conv_tr(self.inplanes, up, kernel_size=2, upsample_stride=2, dilation=1, bias=False, **nb))
       setattr(self, bname, get_norm(self.NORM_TYPE, up, D, bn_momentum=mom))
-      self.inplanes = up + skip_planes[3 - i] * self.BLOCK.expansion
+      self.inplanes = up + skip[i]
       setattr(self, blk, stage(4 + i))
     self.final = conv(self.PLANES[7], out_channels, kernel_size=1, stride=1, bias=True, D=D)
     self.relu = ME.MinkowskiReLU(inplace=True)

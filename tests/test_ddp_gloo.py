@@ -60,3 +60,89 @@ def test_grad_reducer_world2_gloo():
     assert p.exitcode == 0
   assert all(ok for _, ok, _ in out), out
   assert all(abs(l - 1.5) < 1e-6 for _, _, l in out), out
+
+
+def _engine_worker(rank, world, port, q):
+  """The REAL GradReducer driven through NativeEngine._ready_args by a CPU stand-in for pcmi_net_backward's bucket
+  logic (csrc/engine.hip::run_backward: a bucket is final after the lowest-index op that owns parameters of it; the
+  executor reports it by its position in the ASCENDING list of bucket offsets)."""
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  from pointcontrast_amd.engine import NativeEngine, lower_model
+  from pointcontrast_amd.lib import distributed as du
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.model import load_model
+  du.init_process_group(rank, world, backend="gloo")
+  torch.manual_seed(0)
+  model = load_model("Res16UNet14")(3, 32, get_config([]), D=3)
+  flat = du.FlatParameters(model.parameters())
+  red = du.GradReducer(flat, bucket_mb=4.0)
+  assert red.active and len(red.buckets) >= 3
+  prog = lower_model(model, flat)
+  cb, lo_arr, nb = NativeEngine._ready_args(red)
+  lo = [lo_arr[i] for i in range(nb)]
+  assert lo == sorted(lo) and lo[0] == 0 and nb == len(red.buckets)
+
+  def bucket_of(off):
+    b = 0
+    for qq in range(nb):
+      if off >= lo[qq]:
+        b = qq
+    return b
+
+  ops = prog["ops"]
+  last = [-1] * nb
+  for i in range(len(ops) - 1, -1, -1):
+    o = ops[i]
+    if o["type"] == 2:
+      continue
+    last[bucket_of(o["w_off"])] = i
+    if o["type"] == 1 or o.get("has_bias"):
+      last[bucket_of(o["b_off"])] = i
+  fired = []
+  for it in range(2):  # two iterations: the reducer's bookkeeping must reset
+    flat.zero_grad()
+    for i in range(len(ops) - 1, -1, -1):  # "backward": this op's parameter gradients become final
+      o = ops[i]
+      if o["type"] == 0:
+        K = o["kernel_size"] ** 3
+        flat.g[o["w_off"]:o["w_off"] + K * o["cin"] * o["cout"]] += float(rank + 1) * (1 + i % 7)
+        if o.get("has_bias"):
+          flat.g[o["b_off"]:o["b_off"] + o["cout"]] += float(rank + 1)
+      elif o["type"] == 1:
+        flat.g[o["w_off"]:o["w_off"] + o["cout"]] += float(rank + 1) * 2
+        flat.g[o["b_off"]:o["b_off"] + o["cout"]] += float(rank + 1) * 3
+      for b in range(nb):
+        if last[b] == i:
+          n_before = red.n_launched_total
+          cb(None, b)
+          assert red.n_launched_total == n_before + 1, "bucket %d launched twice or not at all" % b
+          if it == 0:
+            fired.append(b)
+    red.finish()
+  assert red.n_launched_total == 2 * nb
+  # expected: the sum over ranks of what each rank wrote (rank + 1 -> 1 + 2 = 3 with world 2)
+  ok = True
+  tot = sum(r + 1 for r in range(world))
+  for i, o in enumerate(ops):
+    if o["type"] == 0:
+      K = o["kernel_size"] ** 3
+      ok &= bool((flat.g[o["w_off"]:o["w_off"] + K * o["cin"] * o["cout"]] == tot * (1 + i % 7)).all())
+    elif o["type"] == 1:
+      ok &= bool((flat.g[o["w_off"]:o["w_off"] + o["cout"]] == tot * 2).all() and (flat.g[o["b_off"]:o["b_off"] + o["cout"]] == tot * 3).all())
+  q.put((rank, ok, fired == sorted(fired, reverse=True), nb))
+  du.destroy_process_group()
+
+
+def test_reducer_through_engine_bucket_mapping_world2_gloo():
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  out = [q.get(timeout=180) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert all(ok for _, ok, _, _ in out), out
+  assert all(desc for _, _, desc, _ in out), "buckets must become final from the END of the flat buffer: %r" % (out,)

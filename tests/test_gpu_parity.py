@@ -757,7 +757,7 @@ def test_rccl_reducer_path_single_rank():
     losses = {}
     for force in (False, True):
       cfg = get_config(["net.model=Res16UNet14", "misc.nceT=0.4", "misc.npos=256", "misc.bucket_mb=4",
-                        "misc.force_reducer=%s" % force])
+                        "misc.force_reducer=%s" % force, "misc.reducer_profile=%s" % force])
       torch.manual_seed(7)
       tr = ddp_trainer.PointNCELossTrainer(cfg, FixedBatchLoader([batch], 2))
       pp = batch["correspondences"].numpy()
@@ -771,6 +771,9 @@ def test_rccl_reducer_path_single_rank():
       if force:
         assert tr.reducer.active and len(tr.reducer.buckets) >= 3
         assert tr.reducer.n_launched_total == 2 * len(tr.reducer.buckets)
+        torch.cuda.synchronize()
+        rep = tr.reducer.overlap_report()  # what bench.py --gpus N prints as config.collective.overlap
+        assert rep["steps"] == 2 and len(rep["buckets"]) == len(tr.reducer.buckets) and rep["exposed_after_backward_ms"] >= 0
     assert losses[True] == losses[False], losses
   finally:
     du.destroy_process_group()
