@@ -9,6 +9,7 @@
 //    min / arg-min are reduced across the quarter wave; the false-negative filter is a device
 //    hash set of int64 pair keys.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "internal.h"
@@ -63,11 +64,15 @@ __device__ inline void dot_tile(const float (*sa)[kTile + 4], const float (*sb)[
   }
 }
 
-// ---- NCE forward: lse[i], per-block partial of sum_i (lse_i - s_ii) -----------------------------
+// ---- NCE forward ------------------------------------------------------------------------------------
+// grid = (row tiles, key splits): a row tile of 64 queries alone is 64 workgroups at n = 4096 -- a quarter of the
+// chip -- so the key tiles are divided over gridDim.y workgroups, each leaving the online log-sum-exp state (m, l)
+// and the diagonal logit of its share in part_m / part_l / part_d [split][n]; nce_combine_kernel merges the splits
+// (same max-rescaled combine as across the 16 lanes of a row) into lse[i] and the loss partials.
 template <int C>
 __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      int64_t n, float inv_T, float* __restrict__ lse,
-                                                      float* __restrict__ part) {
+                                                      int64_t n, float inv_T, int64_t span, float* __restrict__ part_m,
+                                                      float* __restrict__ part_l, float* __restrict__ part_d) {
   __shared__ __attribute__((aligned(16))) float sq[C][kTile + 4];
   __shared__ __attribute__((aligned(16))) float sk[C][kTile + 4];
   __shared__ float s_part[4];
@@ -81,7 +86,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
     l[i] = 0.f;
     diag[i] = 0.f;
   }
-  for (int64_t c0 = 0; c0 < n; c0 += kTile) {
+  const int64_t cbeg = (int64_t)blockIdx.y * span, cend = min(n, cbeg + span);
+  for (int64_t c0 = cbeg; c0 < cend; c0 += kTile) {
     __syncthreads();
     load_tile_dmajor<C>(k, n, c0, sk, t);
     __syncthreads();
@@ -108,7 +114,6 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
     }
   }
   // combine the 16 lanes that share the rows
-  float contrib = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -120,20 +125,41 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
       diag[i] += __shfl_xor(diag[i], d, 64);
     }
     const int64_t row = r0 + tr * 4 + i;
-    if (row < n) {
-      const float v = m[i] + logf(l[i]);
-      if (tc == 0) {
-        lse[row] = v;
-        contrib += v - diag[i];
-      }
+    if (row < n && tc == 0) {
+      const int64_t o = (int64_t)blockIdx.y * n + row;
+      part_m[o] = m[i];
+      part_l[o] = l[i];
+      part_d[o] = diag[i];  // non-zero only in the split that holds column `row`
     }
   }
-  // block sum of contrib (only tc == 0 lanes hold something)
+  (void)s_part;
+}
+
+// lse[i] = log sum_j exp(s_ij) from the per-split (m, l); part[block] = sum over the block's rows of (lse_i - s_ii)
+__global__ __launch_bounds__(256) void nce_combine_kernel(const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                                          const float* __restrict__ part_d, int splits, int64_t n,
+                                                          float* __restrict__ lse, float* __restrict__ part) {
+  __shared__ float s_part[4];
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float contrib = 0.f;
+  if (row < n) {
+    float m = -INFINITY, l = 0.f, dg = 0.f;
+    for (int sp = 0; sp < splits; ++sp) {
+      const float om = part_m[(int64_t)sp * n + row], ol = part_l[(int64_t)sp * n + row];
+      const float nm = fmaxf(m, om);
+      l = (m == -INFINITY ? 0.f : l * expf(m - nm)) + (om == -INFINITY ? 0.f : ol * expf(om - nm));
+      m = nm;
+      dg += part_d[(int64_t)sp * n + row];
+    }
+    const float v = m + logf(l);
+    lse[row] = v;
+    contrib = v - dg;
+  }
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) contrib += __shfl_xor(contrib, d, 64);
-  if ((t & 63) == 0) s_part[t >> 6] = contrib;
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = contrib;
   __syncthreads();
-  if (t == 0) part[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  if (threadIdx.x == 0) part[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
 __global__ void sum_scale_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
@@ -147,10 +173,13 @@ __global__ void sum_scale_kernel(const float* __restrict__ part, int n, float sc
 // ---- NCE backward: d_own[a] = gs * sum_b (softmax - I)[.,.] other_b ------------------------------
 // FOR_K == false: own = q (rows a = i), other = k;   p = exp(s_ab - lse[a])
 // FOR_K == true : own = k (rows a = j), other = q;   p = exp(s_ab - lse[b])
+// grid = (row tiles, splits of the other operand's tiles); with gridDim.y > 1 every split writes its share of the sum to
+// d_part[split][n][C] and nce_sum_splits_kernel adds the shares in split order (deterministic).
 template <int C, bool FOR_K>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ own, const float* __restrict__ other,
                                                       const float* __restrict__ lse, int64_t n, float inv_T,
-                                                      const float* __restrict__ gscale, float* __restrict__ d_own) {
+                                                      const float* __restrict__ gscale, int64_t span,
+                                                      float* __restrict__ d_own) {
   __shared__ __attribute__((aligned(16))) float so[C][kTile + 4];
   __shared__ __attribute__((aligned(16))) float sx[C][kTile + 4];
   __shared__ __attribute__((aligned(16))) float sxr[kTile][C + 4];
@@ -169,7 +198,9 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
   float lse_own[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) lse_own[i] = (!FOR_K && r0 + tr * 4 + i < n) ? lse[r0 + tr * 4 + i] : 0.f;
-  for (int64_t c0 = 0; c0 < n; c0 += kTile) {
+  const int64_t cbeg = (int64_t)blockIdx.y * span, cend = min(n, cbeg + span);
+  d_own += (int64_t)blockIdx.y * n * C;  // this split's share (the caller passes d_part when gridDim.y > 1)
+  for (int64_t c0 = cbeg; c0 < cend; c0 += kTile) {
     __syncthreads();
     load_tile_dmajor<C>(other, n, c0, sx, t);
     load_tile_rowmajor<C>(other, n, c0, sxr, t);
@@ -203,6 +234,22 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < CD; ++d) d_own[(r0 + orow) * C + od0 + d] = dacc[d];
   }
+}
+
+// out[e] = sum over the splits of part[split][e] (float4 per thread, split order)
+__global__ __launch_bounds__(256) void nce_sum_splits_kernel(const float* __restrict__ part, int splits, int64_t n4,
+                                                             float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  float4 s = reinterpret_cast<const float4*>(part)[e];
+  for (int sp = 1; sp < splits; ++sp) {
+    const float4 v = reinterpret_cast<const float4*>(part)[(int64_t)sp * n4 + e];
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[e] = s;
 }
 
 // ---- pdist + argmin ------------------------------------------------------------------------------
@@ -561,9 +608,26 @@ int pcmi_scatter_add_rows(const float* src, int64_t src_ld, const int64_t* idx, 
   return PCMI_OK;
 }
 
+}  // extern "C"
+
+namespace pcmi {
+// workgroups per row tile: enough to put ~2 workgroups on every CU, at most one split per other-operand tile
+static int nce_splits(int64_t n) {
+  const int64_t nb = ceil_div(n, kTile);
+  const char* e = getenv("PCMI_NCE_SPLITS");
+  const int64_t want = e ? atoll(e) : ceil_div(2 * (int64_t)num_cu(), nb);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, nb), 32));
+}
+static int64_t nce_span(int64_t n, int splits) { return ceil_div(ceil_div(n, kTile), splits) * kTile; }
+}  // namespace pcmi
+
+extern "C" {
+
 size_t pcmi_nce_workspace_bytes(int64_t n, int c) {
-  (void)c;
-  return (size_t)(ceil_div(n, kTile) + 1) * sizeof(float) + 256;
+  const size_t sp = 32;  // upper bound of nce_splits
+  // forward: 3 x [splits][n] + the block partials; backward: [splits][n][c] per operand
+  return std::max(sp * (size_t)n * 3 * sizeof(float), sp * (size_t)n * c * sizeof(float)) +
+         (size_t)(ceil_div(n, 256) + 1) * sizeof(float) + 1024;
 }
 
 int pcmi_nce_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, float* lse, float* loss, void* ws,
@@ -573,31 +637,47 @@ int pcmi_nce_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, 
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_nce_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "nce_fwd: workspace too small");
   PCMI_REQUIRE((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0, PCMI_ERR_INVALID, "nce_fwd: q/k must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  const int nb = (int)ceil_div(n, kTile);
-  float* part = (float*)ws;
-  if (c == 16) nce_fwd_kernel<16><<<nb, 256, 0, st>>>(q, k, n, inv_T, lse, part);
-  if (c == 32) nce_fwd_kernel<32><<<nb, 256, 0, st>>>(q, k, n, inv_T, lse, part);
+  const int nb = (int)ceil_div(n, kTile), splits = nce_splits(n), nb2 = (int)ceil_div(n, 256);
+  const int64_t span = nce_span(n, splits);
+  float* pm = (float*)ws;
+  float* pl = pm + (size_t)splits * n;
+  float* pd = pl + (size_t)splits * n;
+  float* part = pd + (size_t)splits * n;
+  const dim3 grid((unsigned)nb, (unsigned)splits);
+  if (c == 16) nce_fwd_kernel<16><<<grid, 256, 0, st>>>(q, k, n, inv_T, span, pm, pl, pd);
+  if (c == 32) nce_fwd_kernel<32><<<grid, 256, 0, st>>>(q, k, n, inv_T, span, pm, pl, pd);
   PCMI_LAUNCH_CHECK();
-  sum_scale_kernel<<<1, 64, 0, st>>>(part, nb, 1.0f / (float)n, loss);
+  nce_combine_kernel<<<nb2, 256, 0, st>>>(pm, pl, pd, splits, n, lse, part);
+  PCMI_LAUNCH_CHECK();
+  sum_scale_kernel<<<1, 64, 0, st>>>(part, nb2, 1.0f / (float)n, loss);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
 
 int pcmi_nce_bwd(const float* q, const float* k, const float* lse, int64_t n, int c, float inv_T, const float* gscale,
                  float* dq, float* dk, void* ws, size_t ws_bytes, pcmi_stream_t stream) {
-  (void)ws;
-  (void)ws_bytes;
   PCMI_REQUIRE(q && k && lse && dq && dk && n > 0, PCMI_ERR_INVALID, "nce_bwd: bad argument");
   PCMI_REQUIRE(c == 16 || c == 32, PCMI_ERR_UNSUPPORTED, "nce_bwd: feature width %d not in {16,32}", c);
   hipStream_t st = as_stream(stream);
-  const int nb = (int)ceil_div(n, kTile);
-#define PCMI_NCE_BWD(CC)                                                               \
-  nce_bwd_kernel<CC, false><<<nb, 256, 0, st>>>(q, k, lse, n, inv_T, gscale, dq);      \
-  nce_bwd_kernel<CC, true><<<nb, 256, 0, st>>>(k, q, lse, n, inv_T, gscale, dk);
-  if (c == 16) { PCMI_NCE_BWD(16) }
-  if (c == 32) { PCMI_NCE_BWD(32) }
-#undef PCMI_NCE_BWD
-  PCMI_LAUNCH_CHECK();
+  const int nb = (int)ceil_div(n, kTile), splits = nce_splits(n);
+  const int64_t span = nce_span(n, splits);
+  PCMI_REQUIRE(splits == 1 || (ws && ws_bytes >= pcmi_nce_workspace_bytes(n, c)), PCMI_ERR_WORKSPACE, "nce_bwd: workspace too small");
+  PCMI_REQUIRE((uintptr_t)dq % 16 == 0 && (uintptr_t)dk % 16 == 0, PCMI_ERR_INVALID, "nce_bwd: dq/dk must be 16-byte aligned");
+  const dim3 grid((unsigned)nb, (unsigned)splits);
+  const int64_t n4 = n * c / 4;
+  for (int which = 0; which < 2; ++which) {  // 0: dq, 1: dk
+    float* dst = which ? dk : dq;
+    float* target = splits > 1 ? (float*)ws : dst;
+    if (c == 16 && !which) nce_bwd_kernel<16, false><<<grid, 256, 0, st>>>(q, k, lse, n, inv_T, gscale, span, target);
+    if (c == 16 && which) nce_bwd_kernel<16, true><<<grid, 256, 0, st>>>(k, q, lse, n, inv_T, gscale, span, target);
+    if (c == 32 && !which) nce_bwd_kernel<32, false><<<grid, 256, 0, st>>>(q, k, lse, n, inv_T, gscale, span, target);
+    if (c == 32 && which) nce_bwd_kernel<32, true><<<grid, 256, 0, st>>>(k, q, lse, n, inv_T, gscale, span, target);
+    PCMI_LAUNCH_CHECK();
+    if (splits > 1) {
+      nce_sum_splits_kernel<<<(unsigned)ceil_div(n4, 256), 256, 0, st>>>((const float*)ws, splits, n4, dst);
+      PCMI_LAUNCH_CHECK();
+    }
+  }
   return PCMI_OK;
 }
 

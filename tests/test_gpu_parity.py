@@ -708,6 +708,15 @@ def test_trainer_iteration_matches_oracle(which):
     else:
       draws = dict(sel0=r.choice(N0, 256, replace=False), sel1=r.choice(N1, 256, replace=False),
                    pos_sel=r.choice(len(pp), 512, replace=False))
+    # every step starts from the DEVICE's state (weights, BN buffers, SGD momentum): an iteration at lr 0.1 amplifies
+    # fp32 round-off of ill-conditioned gradient tensors into 1e-3..1e-2 differences of the next step's features, which
+    # would turn the per-step 1e-4 loss check (and the arg-min check of the hardest loss) into a comparison of two
+    # slightly different networks.  The step itself -- 2 forwards, loss, backward, SGD -- is compared every time.
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in trainer.model.state_dict().items()})
+    if step > 0:
+      dev_params = dict(trainer.model.named_parameters())
+      for name, p in ref.named_parameters():
+        opt.state[p]["momentum_buffer"] = trainer.optimizer.state[dev_params[name]]["momentum_buffer"].detach().cpu().clone()
     res = trainer._train_iter(it, timers, draws=draws)
     opt.zero_grad()
     F0 = ref(sr.SparseTensorRef(batch["sinput0_F"], coords=batch["sinput0_C"].numpy())).F
@@ -728,10 +737,10 @@ def test_trainer_iteration_matches_oracle(which):
   dsd = trainer.model.state_dict()
   report = sorted(((rel_err(dsd[k], v), k) for k, v in ref.state_dict().items() if v.dtype.is_floating_point), reverse=True)
   msg = "; ".join("%s %.2e" % (k, e) for e, k in report[:6])
-  print("worst state tensors after 2 steps:", msg)
-  # two SGD steps at lr 0.1 amplify fp32 gradient noise of ill-conditioned tensors; the loss trace above is
-  # the tight check, this one guards against gross errors
-  assert report[0][0] <= 5e-2, "state after 2 steps: " + msg
+  print("worst state tensors after the last step:", msg)
+  # one SGD step at lr 0.1 (with momentum from the first) from identical state: the update is lr * (fp32 gradient),
+  # whose ill-conditioned tensors carry ~1e-3 relative noise; the loss trace above is the tight check
+  assert report[0][0] <= 2e-2, "state after the step: " + msg
 
 
 def test_rccl_reducer_path_single_rank():
