@@ -147,6 +147,20 @@ def kernel_rooflines(batch, device):
   conv_entry("spconv_mfma pair fwd 2^3/s2^T 96->96 (scatter)", 96, 96, m2, 8, m2.n_out, m2.n_in, transpose=True)
   m1 = cm.kernel_map(ck, ck, 3, 1, 3)
   conv_entry("spconv_mfma fwd 3^3 32->32 @level2", 32, 32, m1, 27, m2.n_out, m2.n_out)
+  conv_entry("stem32_fwd 3^3 3->32 @level1 (lane per row)", 3, 32, cm.kernel_map(key, key, 3, 1, 0), 27, n, n)
+  # PointInfoNCE block, n = 4096 positives, 32 channels: logits GEMM forward, (recompute + contraction) x 2 backward
+  qn = torch.nn.functional.normalize(torch.randn(4096, 32, device=device), dim=1).requires_grad_(True)
+  kn = torch.nn.functional.normalize(torch.randn(4096, 32, device=device), dim=1).requires_grad_(True)
+
+  def nce_step():
+    qn.grad = kn.grad = None
+    PF.NCELossFunction.apply(qn, kn, 0.4).backward()
+
+  t = time_kernel(nce_step)
+  fl = 5 * 2 * 4096 * 4096 * 32
+  out.append({"kernel": "nce fwd + bwd, n=4096 c=32 (5 tile GEMMs, fp32 VALU)", "ms": round(t * 1e3, 4), "gflop": round(fl * 1e-9, 3),
+              "bound": "mfma", "achieved": round(fl / t * 1e-12, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+              "frac": round(fl / t * 1e-12 / PEAK_FP32_MFMA_TFLOPS, 4)})
   # BatchNorm (train) fused with ReLU on [n, 96]: 2 reads + 1 write of the activation
   x = torch.randn(n, 96, device=device)
   gam, bet = torch.ones(96, device=device), torch.zeros(96, device=device)
@@ -348,11 +362,10 @@ def main():
           per_launch = json.load(f)["bytes_per_launch"]
         # the unit-balanced launch of this conv = main kernel + fix-up kernel (in pmc_probe.py only the 96->96 conv
         # takes that launch, so the fix-up's per-launch average belongs to this shape)
-        traffic = per_launch.get("spconv_mfma_kernel<3, 4, false, false, 2, true>")
-        if traffic is not None:
-          traffic += per_launch.get("sk_fixup_kernel", 0.0)
-        else:
-          traffic = per_launch.get("spconv_mfma_kernel<3, 4, false, false, 2, false>")
+        for name in ("spconv16_kernel<3, false, true>", "spconv_mfma_kernel<3, 4, false, false, true, 32, 256>"):
+          if name in per_launch:
+            traffic = per_launch[name] + per_launch.get("sk_fixup_kernel", 0.0)
+            break
       except (OSError, ValueError, KeyError):
         pass
       out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],

@@ -821,24 +821,36 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // accumulators in registers and writes one contiguous 128-byte output row.  HBM-bound: 27 x 4 B of table + <= 27 x 12 B
 // of input + 128 B of output per row.  (stem_fwd_kernel above spends a 10 KB LDS weight staging per 8 rows and reads
 // every table entry / input value 32 times.)
+template <int K>
 __global__ __launch_bounds__(256) void stem32_fwd_kernel(const float* __restrict__ x, int64_t x_ld,
                                                          const float* __restrict__ w /* [K][3][32] */,
-                                                         const int32_t* __restrict__ nbr, int K, int64_t n_rows,
+                                                         const int32_t* __restrict__ nbr, int64_t n_rows,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          int64_t out_ld) {
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= n_rows) return;
+  // all K table entries first, then all K input rows: two memory latencies per output row instead of 2 K
+  int32_t idx[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) idx[k] = nbr ? nbr[(int64_t)k * n_rows + row] : (int32_t)row;
+  float xv[K][3];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float* xp = x + (int64_t)max(idx[k], 0) * x_ld;
+    const bool ok = idx[k] >= 0;
+    xv[k][0] = ok ? xp[0] : 0.f;
+    xv[k][1] = ok ? xp[1] : 0.f;
+    xv[k][2] = ok ? xp[2] : 0.f;
+  }
   float acc[32];
 #pragma unroll
   for (int n = 0; n < 32; ++n) acc[n] = bias ? bias[n] : 0.f;
+#pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int32_t idx = nbr ? nbr[(int64_t)k * n_rows + row] : (int32_t)row;
-    if (idx < 0) continue;
-    const float* xp = x + (int64_t)idx * x_ld;
-    const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+    if (idx[k] < 0) continue;  // (an absent neighbour must not contribute: 0 * w could still be -0 / NaN-propagating)
     const float* wk = w + k * 96;
 #pragma unroll
-    for (int n = 0; n < 32; ++n) acc[n] = fmaf(x2, wk[64 + n], fmaf(x1, wk[32 + n], fmaf(x0, wk[n], acc[n])));
+    for (int n = 0; n < 32; ++n) acc[n] = fmaf(xv[k][2], wk[64 + n], fmaf(xv[k][1], wk[32 + n], fmaf(xv[k][0], wk[n], acc[n])));
   }
   float4* op = reinterpret_cast<float4*>(out + row * out_ld);
 #pragma unroll
@@ -1170,9 +1182,9 @@ int spconv_forward_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, co
                  "spconv_fwd: cin=%d only supported as the 3-channel stride-1 stem", cin);
     if (n_out == 0) return PCMI_OK;
     const int K = map ? map->K : 1;
-    if (cout == 32 && out_ld % 4 == 0 && (uintptr_t)out % 16 == 0) {
-      stem32_fwd_kernel<<<dim3((unsigned)ceil_div(n_out, 256)), 256, 0, st>>>(in, in_ld, weight, map ? map->nbr : nullptr, K,
-                                                                             n_out, bias, out, out_ld);
+    if (cout == 32 && K == 27 && out_ld % 4 == 0 && (uintptr_t)out % 16 == 0) {
+      stem32_fwd_kernel<27><<<dim3((unsigned)ceil_div(n_out, 256)), 256, 0, st>>>(in, in_ld, weight, map->nbr, n_out, bias, out,
+                                                                                 out_ld);
       PCMI_LAUNCH_CHECK();
       return PCMI_OK;
     }

@@ -8,7 +8,7 @@ import collections, csv, json, os, re, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 
 
 def load(name):
@@ -36,7 +36,7 @@ for line in open(os.path.join(src, "pmc_FETCH_SIZE.log")):
     algo[line.split()[2]] = {k: int(v) for k, v in m.items()}
 rows, traffic = [], {}
 for k in F:
-  if not any(x in k for x in ("spconv_mfma", "wgrad_mfma", "sk_fixup", "eltwise_kernel<2>")):
+  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "sk_fixup", "eltwise_kernel<2>")):
     continue
   rd = mean(F[k]["FETCH_SIZE"]) * 1024 * f_scale
   wr = mean(W[k]["WRITE_SIZE"]) * 1024 * w_scale if k in W else float("nan")

@@ -87,4 +87,6 @@ def test_segmentation_head_forward_loss_and_head_gradients(ME, engine):
     eng.backward(0, yd.grad)
   assert_close(dev.final.kernel.grad, ref.final.kernel.grad, 1e-4, "head kernel gradient")
   assert_close(dev.final.bias.grad, ref.final.bias.grad, 1e-4, "head bias gradient")
-  assert_close(dev.block8[0].norm2.bn.bias.grad, ref.block8[0].norm2.bn.bias.grad, 2e-3, "a gradient upstream of the head")
+  # upstream of the head through ONE ReLU only (deeper tensors need the mask-injected comparison of
+  # test_network_features_loss_and_grads: an activation on the kink moves them by percents)
+  assert_close(dev.block8[-1].norm2.bn.bias.grad, ref.block8[-1].norm2.bn.bias.grad, 1e-3, "a gradient upstream of the head")
