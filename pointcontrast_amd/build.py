@@ -16,7 +16,7 @@ BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libpcmi.so")
 SOURCES = ["coords.hip", "spconv.hip", "spconv_wgrad.hip", "norm.hip", "loss.hip", "engine.hip", "sortrows.hip", "widths.hip", "loader.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("PCMI_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

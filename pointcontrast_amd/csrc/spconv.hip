@@ -455,9 +455,16 @@ __global__ __launch_bounds__(TH, TH == 64 ? 2 : (KC > 32 ? 2 : 3)) void spconv_m
 // channels {c0 + 16 blk + 4 kk + s}, and the B fragment uses the same bijection.  One B fragment (ds_read_b32, 2 NT
 // per step) serves both row groups.  LDB = NS + 4 keeps those reads bank-conflict free (4 LDB = 16 mod 32).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// waves per SIMD the 16-row kernel is compiled for: 4 for NT <= 3 (128 VGPRs, 2-5 dwords of scratch outside the
+// MFMA loop) -- measured 3-5 % faster than 3 waves on the level-1 / level-2 convs (scripts/kbench.py); build with
+// -DPCMI_CONV16_W4=0 (PCMI_EXTRA_HIPCC_FLAGS) for the 3-wave form
+#ifndef PCMI_CONV16_W4
+#define PCMI_CONV16_W4 1
+#endif
+__host__ __device__ constexpr int kConv16Waves(int nt) { return (PCMI_CONV16_W4 && nt <= 3) ? 4 : 3; }
 
 template <int NT, bool WT, bool SK>
-__global__ __launch_bounds__(256, 3) void spconv16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArgs a) {
   constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
   constexpr int LDB = NS + 4;
   constexpr int KSLOTS = PCMI_MAX_KERNEL_VOLUME;
@@ -885,13 +892,15 @@ static int64_t sk_min_tiles() {  // read per call: the parity test compares both
   const char* e = getenv("PCMI_SPCONV_STREAMK");
   return e ? (int64_t)atoll(e) : (int64_t)kStreamKDefaultMinTiles;
 }
-static int sk_workgroups() { return 3 * num_cu() / 8 * 8; }  // resident workgroups (3 waves/SIMD), multiple of 8
+// resident workgroups of the unit-balanced launch (3 or 4 waves per SIMD, see kConv16Waves), multiple of 8
+static int sk_workgroups(int NT = 4) { return kConv16Waves(NT) * num_cu() / 8 * 8; }
+static int sk_workgroups_max() { return 4 * num_cu() / 8 * 8; }
 static bool sk_rows_eligible(int64_t rows, int K) {
   const int64_t mt = sk_min_tiles();
   return K > 1 && mt > 0 && rows >= 4096 /* kSortRowsMin: such maps carry tile units */ && ceil_div(rows, 128) >= mt;
 }
 static size_t sk_partial_bytes(int64_t rows, int N, int K) {
-  return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups() * 2 * 128 * N * sizeof(float) : 0;
+  return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups_max() * 2 * 128 * N * sizeof(float) : 0;
 }
 
 // The 16-row kernel takes the 128-row tiles of levels with at least PCMI_CONV16 rows (default 8192; 0 = never, 1 =
@@ -1103,7 +1112,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
       map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64) {
-    const int G = sk_workgroups();
+    const int G = conv16_enabled(n_rows) ? sk_workgroups(p.NT) : sk_workgroups(4);
     const size_t need = sk_partial_bytes(n_rows, N, a.K);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
     a.sk_mask = map->tile_mask;

@@ -42,18 +42,22 @@ def run(label, kmap, K, cin, cout, n_in, n_out, transpose=0):
 
 shapes = {0: [(128, 96), (96, 96), (32, 32)], 1: [(32, 32), (128, 96), (96, 96)], 2: [(32, 64), (64, 64), (192, 128), (128, 128)],
           3: [(64, 128), (128, 128), (384, 256), (256, 256)], 4: [(128, 256), (256, 256)]}
+only = os.environ.get("KBENCH_LEVELS")  # e.g. "0" or "0,1": only the 3^3 convs of these levels, nothing else
+if only is not None:
+  shapes = {l: v for l, v in shapes.items() if str(l) in only.split(",")}
 for lvl, lst in shapes.items():
   m = cm.kernel_map(keys[lvl], keys[lvl], 3, 1, 3)
   n = cm.size(keys[lvl])
   for cin, cout in lst:
     run("L%d 3^3 %d->%d" % (lvl, cin, cout), m, 27, cin, cout, n, n)
-for lvl, (c, cu_in, cu_out) in enumerate([(32, 96, 96), (32, 128, 96), (64, 256, 128), (128, 256, 256)]):
+for lvl, (c, cu_in, cu_out) in enumerate([] if only is not None else [(32, 96, 96), (32, 128, 96), (64, 256, 128), (128, 256, 256)]):
   m2 = cm.kernel_map(keys[lvl], keys[lvl + 1], 2, 2, 0)
   run("L%d->%d 2^3/s2 %d->%d" % (lvl, lvl + 1, c, c), m2, 8, c, c, m2.n_in, m2.n_out)
   run("L%d->%d 2^3/s2^T %d->%d" % (lvl + 1, lvl, cu_in, cu_out), m2, 8, cu_in, cu_out, m2.n_out, m2.n_in, 1)
 n0 = cm.size(keys[0])
-run("L0 1x1 128->96", None, 1, 128, 96, n0, n0)
-run("L0 1x1 96->32", None, 1, 96, 32, n0, n0)
+if only is None:
+  run("L0 1x1 128->96", None, 1, 128, 96, n0, n0)
+  run("L0 1x1 96->32", None, 1, 96, 32, n0, n0)
 print("sum of the listed shapes: fwd %.2f ms, bwd %.2f ms, wgrad %.2f ms" % (tot["fwd"], tot["bwd"], tot["wgrad"]))
 
 # sustained clocks: the same level-1 96->96 forward in consecutive blocks of 100 launches (a drop from the first
