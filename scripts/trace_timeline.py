@@ -40,7 +40,7 @@ def main(path):
     ksum = sum(e - s for s, e, n, q in ks)
     cls = defaultdict(int)
     for s, e, n, q in ks:
-      key = ("spconv" if "spconv_mfma" in n else "wgrad" if "wgrad" in n else "bn" if ("bn_" in n or "colreduce" in n or "colsum" in n) else
+      key = ("spconv" if ("spconv_mfma" in n or "spconv16" in n or "stem" in n) else "wgrad" if "wgrad" in n else "bn" if ("bn_" in n or "colreduce" in n or "colsum" in n) else
              "reduce" if ("reduce" in n or "fixup" in n) else "coords" if any(x in n for x in ("kmap", "scan", "sort", "insert", "stride", "mask", "permute", "tile", "rocprim")) else "other")
       cls[key] += e - s
     print("step %d: wall %.2f ms | GPU busy (any kernel) %.2f ms = %.0f%% | sum of kernel time %.2f ms | %d kernels | queues: %s | %s" %

