@@ -73,13 +73,13 @@ struct ConvArgs {
 
 // Weight chunk [KC x 32*NT] global -> registers -> LDS (NT * KC / 32 float4 per thread).  WT: B[c][n] = W[n][c]
 // (backward-data).
-template <int NT, bool WT, int KC = kKC, int TH = 256>
-__device__ __forceinline__ void load_b_regs(v4f (&breg)[NT * KC * 8 / TH], const float* __restrict__ wb, int64_t w_sc,
+template <int NT, bool WT, int KC = kKC>
+__device__ __forceinline__ void load_b_regs(v4f (&breg)[NT * KC / 32], const float* __restrict__ wb, int64_t w_sc,
                                             int64_t w_sn, int c0, int n0, int t) {
   constexpr int NS = 32 * NT;
 #pragma unroll
-  for (int i = 0; i < NT * KC * 8 / TH; ++i) {
-    const int e = t + i * TH;  // float4 index inside the chunk
+  for (int i = 0; i < NT * KC / 32; ++i) {
+    const int e = t + i * 256;  // float4 index inside the chunk
     if (!WT) {
       const int c = e / (NS / 4), n4 = e % (NS / 4);
       breg[i] = *reinterpret_cast<const v4f*>(wb + (int64_t)(c0 + c) * w_sc + n0 + n4 * 4);
@@ -90,12 +90,12 @@ __device__ __forceinline__ void load_b_regs(v4f (&breg)[NT * KC * 8 / TH], const
   }
 }
 
-template <int NT, bool WT, int LDB, int KC = kKC, int TH = 256>
-__device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT * KC * 8 / TH], float* __restrict__ sb, int t) {
+template <int NT, bool WT, int LDB, int KC = kKC>
+__device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT * KC / 32], float* __restrict__ sb, int t) {
   constexpr int NS = 32 * NT;
 #pragma unroll
-  for (int i = 0; i < NT * KC * 8 / TH; ++i) {
-    const int e = t + i * TH;
+  for (int i = 0; i < NT * KC / 32; ++i) {
+    const int e = t + i * 256;
     if (!WT) {
       const int c = e / (NS / 4), n4 = e % (NS / 4);
       *reinterpret_cast<v4f*>(sb + c * LDB + n4 * 4) = breg[i];
@@ -121,26 +121,17 @@ __device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT * KC * 8 / TH]
 // shorter than the L2 latency of the next step's gathers and weights, so the kernel ran at one memory latency per
 // step (27 steps x ~0.9 us for a 256-channel conv over 1.3k rows); a deeper chunk gives every barrier 4x the matrix
 // work and 4x the loads in flight.  Those variants trade the third wave per SIMD for the larger operand rings.
-//
-// TH: threads per workgroup.  TH = 64 (with RW = 1) is the WAVE-AUTONOMOUS form used for the big levels: one wave is
-// the whole workgroup, owns 32 rows, walks ITS OWN list of occupied offsets and stages its own weight chunks (single
-// LDS buffer -- load, store and use are program-ordered inside one wave), so nothing ever waits for another wave.
-// In the 4-wave form every (tile, offset) step costs the full 48 MFMAs x 64 cycles as soon as ONE of the four waves
-// has a neighbour there (the others idle at the barrier): the step count is set by the 128-row union of the
-// offsets, which is why neither 32- nor 16-row skipping moved the run time.  Price: every wave streams its weight
-// chunk from L2 itself (x4 L2->LDS traffic, ~8 TB/s on the level-1 convs -- well inside the L2's 34 TB/s).
-template <int NT, int RW, bool WT, bool PAIR, bool SK = false, int KC = kKC, int TH = 256>
+template <int NT, int RW, bool WT, bool PAIR, bool SK = false, int KC = kKC>
 // min 3 waves/SIMD: with this bound hipcc keeps the accumulators in plain VGPRs (<= 158 in total, no scratch);
 // without it it split them into AGPRs at 170-220 registers total and 2 waves/SIMD
-__global__ __launch_bounds__(TH, TH == 64 ? 2 : (KC > 32 ? 2 : 3)) void spconv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvArgs a) {
   constexpr int TM = 32 * RW;        // rows per workgroup tile
-  constexpr int KG = (TH / 64) / RW; // wave groups splitting the contraction blocks
-  constexpr int NBUF = TH == 64 ? 1 : 2;  // weight staging buffers
+  constexpr int KG = 4 / RW;         // wave groups splitting the contraction blocks
   constexpr int BPG = KC / 8 / KG;   // eight-channel blocks per wave group per chunk
   constexpr int NS = 32 * NT;        // output-channel slice of this workgroup
   constexpr int LDB = WT ? NS + 1 : NS;
   constexpr int KSLOTS = PAIR ? 1 : PCMI_MAX_KERNEL_VOLUME;
-  constexpr int STAGE_FLOATS = NBUF * KC * LDB;
+  constexpr int STAGE_FLOATS = 2 * KC * LDB;
   constexpr int RED_FLOATS = (KG > 1) ? (KG - 1) * RW * 32 * NS : 0;
   constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
 
@@ -240,7 +231,7 @@ __global__ __launch_bounds__(TH, TH == 64 ? 2 : (KC > 32 ? 2 : 3)) void spconv_m
     if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
     __syncthreads();
     const int cnt = je - jb;
-    for (int p = t; p < cnt * TM; p += TH) {
+    for (int p = t; p < cnt * TM; p += 256) {
       const int kk = p / TM, rr = p - kk * TM;
       const int64_t row = row0 + rr;
       s_idx[kk][rr] = row < a.n_rows ? a.nbr[(int64_t)s_kabs[kk] * a.n_rows + row] : -1;
@@ -257,7 +248,7 @@ __global__ __launch_bounds__(TH, TH == 64 ? 2 : (KC > 32 ? 2 : 3)) void spconv_m
     const int kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
     const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
     if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
-    for (int p = t; p < (kend - kbeg) * TM; p += TH) {
+    for (int p = t; p < (kend - kbeg) * TM; p += 256) {
       const int kk = p / TM, rr = p - kk * TM;
       const int64_t row = row0 + rr;
       int32_t v = -1;
@@ -294,14 +285,14 @@ __global__ __launch_bounds__(TH, TH == 64 ? 2 : (KC > 32 ? 2 : 3)) void spconv_m
   // ---- staging helpers -------------------------------------------------------------------
   // (KC * NS / 4 float4 per chunk -> NT * KC / 32 per thread; kept in registers: the loops
   //  below are fully unrolled over a by-reference array, a lambda capture of it went to scratch)
-  v4f breg[NT * KC * 8 / TH];
+  v4f breg[NT * KC / 32];
   auto load_b = [&](int step) {
     const int kslot = s_klist[step / nch];
     const int c0 = (step % nch) * KC;
     const int wk = PAIR ? a.wsel[k_single] : (SK ? a.wsel[s_kabs[kslot]] : a.wsel[kbeg_blk + kslot]);
-    load_b_regs<NT, WT, KC, TH>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
+    load_b_regs<NT, WT, KC>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
   };
-  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB, KC, TH>(breg, s_f + (buf % NBUF) * (KC * LDB), t); };
+  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB, KC>(breg, s_f + buf * (KC * LDB), t); };
   // A operands (gathers: the long-latency loads) and B chunks (weights: L2 hits shared by every workgroup, through
   // LDS) are both fetched one 32-channel step ahead.  (A two-steps-ahead register ring was measured: no gain once
   // the accumulators stayed in VGPRs, and one wave per SIMD less.)
@@ -338,7 +329,7 @@ __global__ __launch_bounds__(TH, TH == 64 ? 2 : (KC > 32 ? 2 : 3)) void spconv_m
         // Written inline, hipcc emitted ds_read2 -> s_waitcnt lgkmcnt(0) -> 2 MFMAs, i.e. the full LDS latency in
         // front of every 128 cycles of matrix work: SQ_VALU_MFMA_BUSY_CYCLES showed the pipe 52 % busy.  The
         // sched_barriers pin the order (the scheduler otherwise sinks every read next to its use again).
-        const float* sb = s_f + ((step & 1) % NBUF) * (KC * LDB) + r + (8 * (kg * BPG) + 4 * h) * LDB;
+        const float* sb = s_f + (step & 1) * (KC * LDB) + r + (8 * (kg * BPG) + 4 * h) * LDB;
         constexpr int QN = 4 * BPG;                                // contraction steps of this wave per chunk
         constexpr int PF0 = NT >= 3 ? 3 : (NT == 2 ? 4 : 6);       // >= ~380 cycles (6 MFMAs) between read and use
         constexpr int PF = PF0 < QN ? PF0 : QN;
@@ -952,29 +943,6 @@ static bool launch_deep(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   return false;
 }
 
-// Wave-autonomous launch (TH = 64, one 32-row wave per workgroup) for the matrix-bound convs of the big levels:
-// PCMI_WAVE_WG = minimum rows (default 8192; 0 = never).
-// Measured (scripts/kbench.py, level-1 96->96 forward): 0.470 ms against 0.336 ms of the 4-wave unit-balanced launch --
-// the x4 weight streaming and 2 waves per SIMD cost more than the barrier-free steps gain; kept OFF by default as an
-// A/B variant (its parity is covered by the conv tests when PCMI_WAVE_WG is set).
-static bool wave_wg_enabled(int64_t n_rows, int C, int N, int K) {
-  const char* e = getenv("PCMI_WAVE_WG");
-  const int64_t min_rows = e ? atoll(e) : 0;
-  return min_rows > 0 && n_rows >= min_rows && K > 1 && C >= 64 && N >= 64 && N <= 128;
-}
-
-template <bool WT>
-static int launch_wave(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
-  switch (NT) {
-    case 2: spconv_mfma_kernel<2, 1, WT, false, false, kKC, 64><<<grid, 64, 0, st>>>(a); break;
-    case 3: spconv_mfma_kernel<3, 1, WT, false, false, kKC, 64><<<grid, 64, 0, st>>>(a); break;
-    case 4: spconv_mfma_kernel<4, 1, WT, false, false, kKC, 64><<<grid, 64, 0, st>>>(a); break;
-    default: set_error("spconv: bad NT %d for the wave launch", NT); return PCMI_ERR_INVALID;
-  }
-  PCMI_LAUNCH_CHECK();
-  return PCMI_OK;
-}
-
 template <int RW, bool WT, bool PAIR>
 static int launch_nt(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   switch (NT) {
@@ -1100,13 +1068,6 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   if (map && map->perm && map->nbr_perm) {  // same results, rows visited in mask-sorted order
     a.nbr = map->nbr_perm;
     a.perm = map->perm;
-  }
-  if (map && map->stride == 1 && wave_wg_enabled(n_rows, C, N, a.K)) {
-    // one wave per workgroup, 32-row tiles in the XCD-contiguous order of the mask sort, the whole output width
-    const int64_t per_xcd = map->perm ? xcd_chunk_rows(n_rows) / 32 : ceil_div(ceil_div(n_rows, 32), 8);
-    a.xcd_tiles = (int)per_xcd;
-    dim3 grid((unsigned)(per_xcd * 8), 1, 1);
-    return w_transposed ? launch_wave<true>(N / 32, a, grid, st) : launch_wave<false>(N / 32, a, grid, st);
   }
   Plan p = make_plan(n_rows, N, a.K, false);
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
