@@ -93,3 +93,54 @@ def test_segmentation_head_forward_loss_and_head_gradients(ME, engine):
   err = (gd - gr).abs() / gr.abs().max()
   assert int((err > 1e-4).sum()) <= 2 and float(err.max()) <= 1e-2, "upstream gradient: %d channels off, worst %.2e" % (
       int((err > 1e-4).sum()), float(err.max()))
+
+
+def test_segmentation_trainer_steps_match_oracle(tmp_path):
+  """pointcontrast_amd.downstream.semseg.SegmentationTrainer: pre-trained backbone loaded by name and shape (the
+  32-wide contrastive head is skipped), then two fine-tuning iterations -- forward, CE(ignore 255), backward, SGD(0.9)
+  + PolyLR -- against the oracle model + torch CrossEntropyLoss / SGD / the reference's PolyLR formula.  Every step
+  starts from the device's state (see test_trainer_iteration_matches_oracle)."""
+  from oracle import model_ref as mr, sparse_ref as sr
+  from pointcontrast_amd.downstream import semseg as ss
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.model import load_model
+  torch.manual_seed(5)
+  pre = load_model("Res16UNet14")(3, 32, get_config([]), D=3)  # "pre-trained" weights with the contrastive head
+  torch.save({"state_dict": {"module." + k: v for k, v in pre.state_dict().items()}}, tmp_path / "pretrained.pth")
+  tr = ss.SegmentationTrainer(20, model="Res16UNet14", lr=0.05, max_iter=50, pretrained=str(tmp_path / "pretrained.pth"))
+  sd = tr.model.state_dict()
+  assert torch.equal(sd["block3.0.conv1.kernel"].cpu(), pre.state_dict()["block3.0.conv1.kernel"])
+  assert sd["final.kernel"].shape == (256, 20)
+  ref = mr.MODELS["Res16UNet14"](3, 20, bn_momentum=0.02, normalize_feature=False)
+  ref.train()
+  opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, dampening=0, weight_decay=1e-4)
+  b = synthetic.make_batch(seed=8, batch_size=2, crop=0.6)
+  C, F = torch.from_numpy(b["sinput0_C"]), torch.from_numpy(b["sinput0_F"])
+  target = torch.from_numpy(np.random.RandomState(1).randint(0, 20, len(C)))
+  target[::5] = 255
+  for step in range(2):
+    ref.load_state_dict({k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
+    if step > 0:
+      dev_params = dict(tr.model.named_parameters())
+      for name, p in ref.named_parameters():
+        opt.state[p]["momentum_buffer"] = tr.optimizer.state[dev_params[name]]["momentum_buffer"].detach().cpu().clone()
+    lr_now = tr.scheduler.get_last_lr()[0]
+    assert abs(lr_now - 0.05 * (1 - step / 51) ** 0.9) < 1e-9
+    for g in opt.param_groups:
+      g["lr"] = lr_now
+    res = tr.train_iter(C, F, target)
+    opt.zero_grad()
+    logits = ref(sr.SparseTensorRef(F, coords=C.numpy())).F
+    loss = torch.nn.functional.cross_entropy(logits, target, ignore_index=255)
+    loss.backward()
+    opt.step()
+    assert abs(float(res["loss"]) - float(loss)) <= 1e-4 * abs(float(loss)), (step, float(res["loss"]), float(loss))
+    ref_score = ss.precision_at_one(logits.detach().max(1)[1], target)
+    assert abs(res["score"] - ref_score) <= 0.5, (res["score"], ref_score)  # arg-max ties
+  report = sorted(((float((dict(tr.model.named_parameters())[k].detach().cpu() - p.detach()).abs().max()) /
+                    max(float(p.detach().abs().max()), 1e-6), k) for k, p in ref.named_parameters()), reverse=True)
+  print("worst parameters after the fine-tuning step:", report[:4])
+  assert report[0][0] <= 2e-2
+  miou, ious, hist = tr.evaluate(C, F, target.numpy())
+  assert hist.shape == (20, 20) and hist.sum() == int((target != 255).sum()) and 0.0 <= miou <= 100.0

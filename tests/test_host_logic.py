@@ -283,3 +283,39 @@ def test_checkpoint_prefixes_and_kernel_order_switch(built_lib):
   m2 = load_model("Res16UNet14")(3, 32, get_config([]), D=3)
   ck.load_state(m2, {"module." + k: v for k, v in as_file.items()}, kernel_order="hypercube")
   assert torch.equal(m2.state_dict()["block4.0.conv2.kernel"], sd["block4.0.conv2.kernel"])
+
+
+def test_semseg_scheduler_and_metrics_against_reference_source(built_lib):
+  """downstream/semseg pieces restated in pointcontrast_amd/downstream/semseg.py: PolyLR against the reference's own
+  class (lib/solvers.py imports only torch: executed from /root/reference where present), metrics against hand counts."""
+  import importlib.util
+  from pointcontrast_amd.downstream import semseg as ss
+  p = torch.nn.Parameter(torch.zeros(3))
+  opt = torch.optim.SGD([p], lr=0.1, momentum=0.9)
+  sch = ss.PolyLR(opt, max_iter=100, power=0.9)
+  lrs = []
+  for _ in range(5):
+    opt.step()
+    sch.step()
+    lrs.append(sch.get_last_lr()[0])
+  assert abs(lrs[0] - 0.1 * (1 - 1 / 101) ** 0.9) < 1e-12 and lrs == sorted(lrs, reverse=True)
+  ref_path = "/root/reference/downstream/semseg/lib/solvers.py"
+  if os.path.isfile(ref_path):
+    spec = importlib.util.spec_from_file_location("ref_semseg_solvers", ref_path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    opt2 = torch.optim.SGD([torch.nn.Parameter(torch.zeros(3))], lr=0.1, momentum=0.9)
+    sch2 = mod.PolyLR(opt2, max_iter=100, power=0.9)
+    ref_lrs = []
+    for _ in range(5):
+      opt2.step()
+      sch2.step()
+      ref_lrs.append(sch2.get_last_lr()[0])
+    assert ref_lrs == lrs
+  pred = np.array([0, 1, 1, 2, 2, 2, 0])
+  label = np.array([0, 1, 2, 2, 2, 255, 1])
+  h = ss.fast_hist(pred, label, 3)
+  assert h.tolist() == [[1, 0, 0], [1, 1, 0], [0, 1, 2]]
+  iu = ss.per_class_iu(h)
+  assert np.allclose(iu, [1 / 2, 1 / 3, 2 / 3])
+  assert abs(ss.precision_at_one(torch.from_numpy(pred), torch.from_numpy(label)) - 100 * 4 / 6) < 1e-4
