@@ -459,6 +459,9 @@ class MinkowskiBatchNorm(nn.Module):
   def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
     super().__init__()
     assert affine and track_running_stats
+    if num_features % 4 != 0 or num_features > 1024:  # fail at model build, not at the first launch
+      raise ValueError("MinkowskiBatchNorm: libpcmi's normalisation kernels need a channel count that is a multiple "
+                       "of 4 and <= 1024 (got %d)" % num_features)
     self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
     # num_batches_tracked only matters for momentum=None; count on the host and fold it into the
     # buffer when a state_dict is taken instead of launching a 1-element kernel per forward
