@@ -18,8 +18,20 @@ import torch.utils.data
 from scipy.spatial import cKDTree
 
 from . import synthetic
-from . import transforms as t
 from .data_sampler import DistributedInfSampler, InfSampler
+
+
+class FeatureJitter:
+  """The loader's only feature transform (pc/lib/transforms.py:21-30, applied through Compose at
+  pc/lib/ddp_data_loaders.py:281-288): with probability p the features get N(mu, sigma) noise; coordinates pass."""
+
+  def __init__(self, mu=0.0, sigma=0.01, p=0.95):
+    self.mu, self.sigma, self.p = mu, sigma, p
+
+  def __call__(self, coords, feats):
+    if random.random() < self.p:
+      feats = feats + np.random.normal(self.mu, self.sigma, feats.shape)
+    return coords, feats
 
 
 def get_matching_indices(xyz0, xyz1, trans, search_radius, K=None):
@@ -145,7 +157,7 @@ def make_data_loader(config, batch_size, num_threads=0):
   if config.data.dataset not in dataset_str_mapping:
     raise ValueError("Dataset %s does not exist in %s" % (config.data.dataset, ", ".join(dataset_str_mapping)))
   Dataset = dataset_str_mapping[config.data.dataset]
-  dset = Dataset(phase="train", transform=t.Compose([t.Jitter()]), random_scale=config.trainer.use_random_scale,
+  dset = Dataset(phase="train", transform=FeatureJitter(), random_scale=config.trainer.use_random_scale,
                  random_rotation=config.trainer.use_random_rotation, config=config)
   batch_size = batch_size // config.misc.num_gpus  # per-GPU batch, pc/lib/ddp_data_loaders.py:292
   # The training loop calls iter() once and next() until opt.max_iter (pc/lib/ddp_trainer.py:128-140), so the loader
