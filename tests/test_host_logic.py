@@ -319,3 +319,36 @@ def test_semseg_scheduler_and_metrics_against_reference_source(built_lib):
   iu = ss.per_class_iu(h)
   assert np.allclose(iu, [1 / 2, 1 / 3, 2 / 3])
   assert abs(ss.precision_at_one(torch.from_numpy(pred), torch.from_numpy(label)) - 100 * 4 / 6) < 1e-4
+
+
+def test_samplers_reproduce_the_reference_classes():
+  """lib/data_sampler.py against the reference's own InfSampler / DistributedInfSampler (pc/lib/data_sampler.py imports
+  only torch: executed from /root/reference where present): identical index streams AND identical positions of the
+  permutation draws in the global torch RNG stream (other consumers of that stream -- the NCE trainer's Uniform
+  draws -- sit between them)."""
+  import importlib.util
+  path = "/root/reference/pretrain/pointcontrast/lib/data_sampler.py"
+  if not os.path.isfile(path):
+    pytest.skip("/root/reference is not present on this host")
+  spec = importlib.util.spec_from_file_location("ref_sampler", path)
+  ref = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(ref)
+  from pointcontrast_amd.lib import data_sampler as ds
+  data = list(range(11))
+
+  def stream(mod, make, n=45):
+    torch.manual_seed(3)
+    s = make(mod)
+    out = []
+    for i in range(n):
+      out.append(next(s))
+      out.append(float(torch.rand(1)))  # another consumer of the RNG between two indices
+    return out
+
+  for shuffle in (False, True):
+    assert stream(ref, lambda m: m.InfSampler(data, shuffle)) == stream(ds, lambda m: m.InfSampler(data, shuffle))
+  for world in (2, 3, 4):
+    for rank in range(world):
+      mk = lambda m: m.DistributedInfSampler(data, world, rank, True)
+      assert stream(ref, mk) == stream(ds, mk), (world, rank)
+      assert len(mk(ref)) == len(mk(ds))
