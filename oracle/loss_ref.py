@@ -24,11 +24,19 @@ def nce_select_pairs(pos_pairs, uniform, sampled_inds=None):
   return q_unique, k_sel
 
 
-def nce_loss(F0, F1, q_idx, k_idx, T):
+def nce_loss(F0, F1, q_idx, k_idx, T, sampled_inds=None):
   """pc/lib/ddp_trainer.py:409-426 + pc/lib/criterion.py:15-19:
-  CE(q @ k^T / T, arange)."""
+  CE(q @ k^T / T, arange).
+  sampled_inds: the reference gathers in TWO stages (q = F0[q_unique]; q = q[sampled_inds], :409-415); pass the
+  unsampled selection plus sampled_inds to reproduce that spelling (tests/test_reference_trainer_source.py runs it
+  beside the reference's own file).  The loss is the same either way; where several queries picked the same key the
+  gradient w.r.t. F1 is a scatter-add whose last bit depends on the order of the adds (torch's CPU kernel uses parallel
+  atomics unless torch.use_deterministic_algorithms(True))."""
   q = F0[q_idx]
   k = F1[k_idx]
+  if sampled_inds is not None:
+    q = q[sampled_inds]
+    k = k[sampled_inds]
   logits = torch.mm(q, k.t()) / T
   labels = torch.arange(q.shape[0])
   return F.cross_entropy(logits, labels)

@@ -62,3 +62,37 @@ def fill_deterministic(model, seed=0):
         fan = p.numel() // p.shape[-1] if name.endswith(".kernel") else p.shape[-1]
         v = u / max(fan, 1) ** 0.5
       p.copy_(v.to(p.dtype))
+
+
+def import_reference_trainer(install):
+  """pc/lib/ddp_trainer.py (+ its lib.* siblings and the model package), imported unmodified with `MinkowskiEngine`
+  resolved through `install()`.  The two packages it imports that are absent here and irrelevant to the arithmetic
+  (omegaconf, tensorboardX) are satisfied with empty stand-ins; `torch.autograd.set_detect_anomaly(True)`, which the
+  file switches on at import (pc/lib/ddp_trainer.py:36), is switched off again."""
+  import types
+  assert reference_available()
+  _purge()
+  for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.")]:
+    del sys.modules[k]
+  install()
+  if not hasattr(collections, "Sequence"):
+    collections.Sequence = collections.abc.Sequence
+  stubs = {}
+  for name, attr in (("omegaconf", "OmegaConf"), ("tensorboardX", "SummaryWriter")):
+    if name not in sys.modules:
+      m = types.ModuleType(name)
+      setattr(m, attr, type(attr, (), {}))
+      sys.modules[name] = stubs[name] = m
+  sys.path.insert(0, REF_PC)
+  try:
+    mod = importlib.import_module("lib.ddp_trainer")
+  finally:
+    sys.path.remove(REF_PC)
+    torch.autograd.set_detect_anomaly(False)
+    for name in stubs:
+      del sys.modules[name]
+  assert os.path.abspath(mod.__file__).startswith(REF_PC)
+  _purge()
+  for k in [k for k in sys.modules if k == "lib" or k.startswith("lib.")]:
+    del sys.modules[k]
+  return mod
