@@ -72,11 +72,21 @@ def conv_work(model):
   return flops, bytes_, rows
 
 
-def time_kernel(fn, iters=20, warm=3):
+def time_kernel(fn, iters=20, warm=3, warm_ms=40.0):
+  """Average duration of fn() over `iters` back-to-back launches (HIP events on the launch stream), after `warm`
+  launches and at least `warm_ms` of continuous work: the GPU has been idle while the host prepared the operands, and
+  the first launches after an idle period ran up to 10 % slower than the same launch in a busy stream (kbench.py: the
+  shape measured first was always the slow one), which is not the state the training step runs the kernel in."""
+  import time
   import torch
   for _ in range(warm):
     fn()
   torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  while (time.perf_counter() - t0) * 1e3 < warm_ms:
+    for _ in range(8):
+      fn()
+    torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   e0.record()  # libpcmi launches on torch's current stream, the stream these events are recorded on
   for _ in range(iters):
@@ -362,7 +372,8 @@ def main():
           per_launch = json.load(f)["bytes_per_launch"]
         # the unit-balanced launch of this conv = main kernel + fix-up kernel (in pmc_probe.py only the 96->96 conv
         # takes that launch, so the fix-up's per-launch average belongs to this shape)
-        for name in ("spconv16_kernel<3, false, true>", "spconv_mfma_kernel<3, 4, false, false, true, 32, 256>"):
+        for name in ("spconv16p_kernel<3, false, true>", "spconv16_kernel<3, false, true>",
+                     "spconv_mfma_kernel<3, 4, false, false, true, 32, 256>"):
           if name in per_launch:
             traffic = per_launch[name] + per_launch.get("sk_fixup_kernel", 0.0)
             break

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcmi.so")
+# PCMI_LIB: another build of the SAME library (scripts/ablate_conv16.sh's A/B kernels); never a different implementation
+LIB_PATH = os.path.abspath(os.environ["PCMI_LIB"]) if os.environ.get("PCMI_LIB") else os.path.join(_HERE, "libpcmi.so")
 
 if not os.path.exists(LIB_PATH):
   raise ImportError(

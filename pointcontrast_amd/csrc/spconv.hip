@@ -452,6 +452,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PCMI_CONV16_W4
 #define PCMI_CONV16_W4 1
 #endif
+// timing ablations of spconv16_kernel (results are WRONG for != 0; scripts/ablate_conv16.sh builds them into separate
+// libraries): 1 no group skipping, 2 contiguous rows instead of the gather, 3 no B store + barrier per step,
+// 4 no MFMA, 5 no A loads, 9 per-wave cycle accounting, 10 (pipelined form) no progress-based issue priority
+#ifndef PCMI_ABLATE
+#define PCMI_ABLATE 0
+#endif
+#if PCMI_ABLATE == 9  // per-wave cycle accounting of spconv16_kernel (s_memtime), read back by pcmi_debug_conv_prof
+__device__ unsigned long long g_conv16_prof[4096 * 12];
+#define PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define PROF_ADD(slot, d) prof[slot] += (d)
+#else
+#define PROF_T(v)
+#define PROF_ADD(slot, d)
+#endif
 __host__ __device__ constexpr int kConv16Waves(int nt) { return (PCMI_CONV16_W4 && nt <= 3) ? 4 : 3; }
 
 template <int NT, bool WT, bool SK>
@@ -470,6 +484,12 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
   const int n0 = blockIdx.y * NS;
   int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
   bool sk_first = true;
+#if PCMI_ABLATE == 9
+  unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  prof[8] = __builtin_readcyclecounter();
+  prof[9] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+  prof[10] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+#endif
   if constexpr (SK) {
     const int G = (int)gridDim.x;
     sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
@@ -490,6 +510,7 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
     sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);
   }
   for (;;) {  // one pass per tile piece (exactly one when !SK)
+  PROF_T(pt_piece);
   bool sk_whole = true;
   int sk_next_u = 0;
   int t = threadIdx.x;
@@ -584,8 +605,13 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
     int valid = 0;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const int32_t idx = s_idx[kslot][wave * 32 + g * 16 + i];
-      if (idx >= 0) {
+      int32_t idx = s_idx[kslot][wave * 32 + g * 16 + i];
+      if constexpr (PCMI_ABLATE == 2) {
+        if (idx >= 0) idx = (int32_t)(((SK ? (int64_t)sk_tile : (int64_t)blockIdx.x) * TM + wave * 32 + g * 16 + i) % a.n_rows);
+      }
+      if (PCMI_ABLATE == 5) {
+        dst[g][0] = dst[g][1] = make_float4(1.f, 0.f, 0.f, 0.f);
+      } else if (idx >= 0) {
         const float* xp = a.x + (int64_t)idx * a.x_ld + c0 + 4 * kk;
         dst[g][0] = *reinterpret_cast<const float4*>(xp);
         dst[g][1] = *reinterpret_cast<const float4*>(xp + 16);
@@ -594,19 +620,29 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
       }
       valid |= __any(idx >= 0) ? (1 << g) : 0;
     }
-    return valid;
+    return PCMI_ABLATE == 1 ? 3 : valid;
   };
 
+  PROF_T(pt_pro);
+  PROF_ADD(0, pt_pro - pt_piece);
   if (nsteps > 0) {
     load_b(0);
     va0 = load_a(0, a0);
     store_b(0);
     __syncthreads();
+    PROF_T(pt_fill);
+    PROF_ADD(1, pt_fill - pt_pro);
     for (int step = 0; step < nsteps; ++step) {
       const bool more = step + 1 < nsteps;
+      PROF_T(pt0);
       if (more) load_b(step + 1);
       if (more) va1 = load_a(step + 1, a1);
-      if (va0) {
+      PROF_T(pt1);
+      PROF_ADD(2, pt1 - pt0);
+      PROF_ADD(7, (unsigned long long)(((va0 & 1) + ((va0 >> 1) & 1)) * 8 * CTN));
+      if constexpr (PCMI_ABLATE == 4) {
+        acc[0][0][0] += a0[0][0].x + a0[0][1].y + a0[1][0].z + a0[1][1].w;
+      } else if (va0) {
         // B fragments PF contraction steps ahead of their MFMAs (register ring, order pinned by sched_barrier)
         const float* sb = s_f + (step & 1) * (kKC * LDB) + i + (4 * kk) * LDB;
         constexpr int QN = 8, PF = 2;  // 8 contraction steps of 4 channels per lane-quad; >= 256 NT cycles ahead
@@ -640,8 +676,23 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (more) store_b((step + 1) & 1);
-      __syncthreads();
+      PROF_T(pt2);
+      PROF_ADD(3, pt2 - pt1);
+      if constexpr (PCMI_ABLATE == 9) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PROF_T(pt2b);
+        PROF_ADD(4, 1);  // steps (the vmcnt(0) wait measured 0.3 % of the wave time)
+        if (more) store_b((step + 1) & 1);
+        __syncthreads();
+        PROF_T(pt3);
+        PROF_ADD(5, pt3 - pt2b);
+      } else if constexpr (PCMI_ABLATE == 3) {
+        if (more && step < 1) store_b((step + 1) & 1);  // keeps the loaded registers live
+        else if (more) asm volatile("" :: "v"(breg[0].x), "v"(breg[NT - 1].w));
+      } else {
+        if (more) store_b((step + 1) & 1);
+        __syncthreads();
+      }
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         a0[g][0] = a1[g][0];
@@ -684,6 +735,17 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
         }
       }
   }
+  PROF_T(pt_end);
+  PROF_ADD(6, pt_end - pt_piece);
+#if PCMI_ABLATE == 9
+  if (!SK || sk_next_u >= sk_u1) {
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
+      unsigned long long* o = g_conv16_prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12;
+      prof[11] = __builtin_readcyclecounter();
+      for (int q = 0; q < 12; ++q) o[q] = prof[q];
+    }
+  }
+#endif
   if constexpr (!SK) {
     break;
   } else {
@@ -696,16 +758,359 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
   }  // for (;;)
 }
 
+// ---- software-pipelined form of spconv16_kernel ---------------------------------------------------------------------
+// Per-wave cycle accounting of spconv16_kernel (scripts/conv16_prof.py, profiles/r02_conv16_cycles.txt): a wave spent
+// 31 % of its life ISSUING the next step's loads (two dependent LDS look-ups, a kernarg look-up, 64-bit address
+// arithmetic, exec-masked gathers), 33 % in its MFMA phase and 23 % at the per-step barrier; no phase of a wave
+// overlapped another phase of the same wave, so the matrix pipe depended on the other three waves of the SIMD being
+// in their MFMA phase (busy 83 % while all four were alive, 67 % of the kernel: the CU's workgroups finish staggered
+// and the last ones run alone).  Here the next step's loads are issued from INSIDE the MFMA stream:
+//   * the neighbour table is staged as 32-bit BYTE offsets (absent = 0x80000000) and the gathers / weight loads are raw
+//     buffer loads: an absent row is an out-of-range offset that returns zeros -- no exec masking, no 64-bit address
+//     arithmetic, the chunk offset rides in the scalar offset operand;
+//   * one LDS look-up per offset ({table row, weight slice byte offset}), reused by the C / 32 chunk steps of the offset;
+//   * the look-up, the weight loads and the gathers sit after the MFMAs of contraction steps 0, 1 and 2 of the running
+//     chunk, each consuming what the previous stage requested, so none of them waits.
+// Operands, accumulation order and results are those of spconv16_kernel (bit-identical).  Needs the gathered operand
+// to be < 2 GiB (the launcher falls back otherwise).
+template <int NT, bool WT, bool SK>
+__global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvArgs a) {
+  constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;
+  constexpr int LDB = NS + 4;
+  constexpr int KSLOTS = PCMI_MAX_KERNEL_VOLUME;
+  constexpr uint32_t kAbsent = 0x80000000u;
+  constexpr int kRsrcFlags = 0x00020000;  // raw buffer, 32-bit data format
+  __shared__ __attribute__((aligned(16))) float s_f[2 * kKC * LDB];
+  __shared__ uint32_t s_off[KSLOTS][TM];
+  __shared__ int32_t s_orow[TM];
+  __shared__ int2 s_kmeta[KSLOTS];  // per occupied offset: {row of s_off, byte offset of its weight slice}
+  __shared__ int32_t s_kabs[KSLOTS];
+  __shared__ int32_t s_nk;
+  __shared__ int64_t s_tile[2];
+
+  const int n0 = blockIdx.y * NS;
+  int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
+  bool sk_first = true;
+#if PCMI_ABLATE == 9
+  unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  prof[8] = __builtin_readcyclecounter();
+  prof[9] = __builtin_amdgcn_s_getreg(63492);
+  prof[10] = __builtin_amdgcn_s_getreg(63508);
+#endif
+  if constexpr (SK) {
+    const int G = (int)gridDim.x;
+    sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
+    // shares are counted in chunk STEPS (units x C / 32): 15 001 units over 1024 workgroups is 15 units (45 steps) for
+    // most against a mean of 43.95 steps
+    const int U = a.sk_pref[a.sk_tiles] * (a.C / kKC);
+    const int per = (U + G - 1) / G;
+    sk_u = sk_g * per;
+    sk_u1 = min(U, sk_u + per);
+    if (sk_u >= sk_u1) return;
+    if (threadIdx.x < 64) {  // last tile whose first unit is <= sk_u: 64-ary search (two dependent loads for <= 4096 tiles)
+      int lo = 0, n = a.sk_tiles;  // answer in [lo, lo + n)
+      while (n > 1) {
+        const int stride = (n + 63) / 64;
+        const int probe = lo + (int)threadIdx.x * stride;
+        const bool le = probe < lo + n && a.sk_pref[probe] * (a.C / kKC) <= sk_u;
+        const int cnt = __popcll(__ballot(le));  // probes are ordered: the first cnt are <=
+        const int nlo = lo + max(cnt - 1, 0) * stride;
+        n = min(stride, lo + n - nlo);
+        lo = nlo;
+      }
+      if (threadIdx.x == 0) s_tile[0] = lo;
+    }
+    __syncthreads();
+    sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);
+  }
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7FFFFFFF, kRsrcFlags);
+  const uint32_t ld_bytes = (uint32_t)(a.x_ld * 4);
+  const uint32_t wk_bytes = (uint32_t)(a.w_kstride * 4);
+  const int sk_total = SK ? sk_u1 - sk_u : 0;  // chunk steps of this workgroup
+  int sk_done = 0, prio_qtr = -1;
+  for (;;) {  // one pass per tile piece (exactly one when !SK)
+  PROF_T(pt_piece);
+  bool sk_whole = true;
+  int sk_next_u = 0, sk_c0 = 0, sk_steps = 0;  // SK: first chunk of the piece's first offset; steps of the piece
+  int t = threadIdx.x;
+  if constexpr (SK) asm volatile("" : "+v"(t));  // see spconv_mfma_kernel
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  if constexpr (SK) {
+    const int64_t row0 = (int64_t)sk_tile * TM;
+    const uint32_t tmask = a.sk_mask[sk_tile];
+    const int nch_ = a.C / kKC;
+    const int pref = a.sk_pref[sk_tile] * nch_, ns_t = __popc(tmask) * nch_;  // in steps
+    const int jb = sk_u - pref, je = min(sk_u1 - pref, ns_t);                 // this piece: steps [jb, je) of the tile
+    sk_whole = (jb == 0 && je == ns_t);
+    sk_next_u = pref + je;
+    const int o0 = jb / nch_, o1 = (je - 1) / nch_;  // occupied offsets (by rank) the piece touches
+    sk_c0 = jb - o0 * nch_;
+    sk_steps = je - jb;
+    if (t < a.K && ((tmask >> t) & 1u)) {  // lane k: the rank of offset k among the occupied ones
+      const int j = __popc(tmask & ((1u << t) - 1u));
+      if (j >= o0 && j <= o1) {
+        s_kabs[j - o0] = t;
+        s_kmeta[j - o0] = make_int2(j - o0, (int)((uint32_t)a.wsel[t] * wk_bytes));
+      }
+    }
+    if (t == 0) s_nk = sk_steps > 0 ? o1 - o0 + 1 : 0;
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    __syncthreads();
+    const int cnt = sk_steps > 0 ? o1 - o0 + 1 : 0;
+    for (int p = t; p < cnt * TM; p += 256) {
+      const int q = p / TM, rr = p - q * TM;
+      const int64_t row = row0 + rr;
+      const int32_t v = row < a.n_rows ? a.nbr[(int64_t)s_kabs[q] * a.n_rows + row] : -1;
+      s_off[q][rr] = v >= 0 ? (uint32_t)v * ld_bytes : kAbsent;
+    }
+  } else {
+    int64_t tile = blockIdx.x;
+    if (a.xcd_tiles > 0) {
+      tile = (int64_t)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
+      if (tile * TM >= a.n_rows) return;
+    }
+    const int64_t row0 = tile * TM;
+    const int kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
+    const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    for (int p = t; p < (kend - kbeg) * TM; p += 256) {
+      const int q = p / TM, rr = p - q * TM;
+      const int64_t row = row0 + rr;
+      int32_t v = -1;
+      if (row < a.n_rows) v = a.nbr ? a.nbr[(int64_t)(kbeg + q) * a.n_rows + row] : (int32_t)row;
+      s_off[q][rr] = v >= 0 ? (uint32_t)v * ld_bytes : kAbsent;
+    }
+    __syncthreads();
+    if (t < 64) {  // offsets with at least one neighbour in this tile
+      int nk = 0;
+      for (int q = 0; q < kend - kbeg; ++q) {
+        bool any = false;
+        for (int rr = t; rr < TM; rr += 64) any |= (s_off[q][rr] != kAbsent);
+        if (__any(any)) {
+          if (t == 0) s_kmeta[nk] = make_int2(q, (int)((uint32_t)a.wsel[kbeg + q] * wk_bytes));
+          ++nk;
+        }
+      }
+      if (t == 0) s_nk = nk;
+    }
+  }
+  __syncthreads();
+  const int nk = s_nk;
+  const int nch = a.C / kKC;
+  const int nsteps = SK ? sk_steps : nk * nch;
+
+  f32x4 acc[2][CTN];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int ct = 0; ct < CTN; ++ct) acc[g][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this thread's float4s of a weight chunk: byte offsets relative to (slice, chunk)
+  uint32_t bvo[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int e = t + q * 256;
+    if (!WT) {
+      const int c = e / (NS / 4), n4 = e % (NS / 4);
+      bvo[q] = (uint32_t)(((int64_t)c * a.w_sc + n0 + n4 * 4) * 4);
+    } else {
+      const int n = e / (kKC / 4), c4 = e % (kKC / 4);
+      bvo[q] = (uint32_t)(((int64_t)(n0 + n) * a.w_sn + c4 * 4) * 4);
+    }
+  }
+  const uint32_t b_chunk_bytes = (uint32_t)((WT ? (int64_t)kKC : (int64_t)kKC * a.w_sc) * 4);
+  v4f breg[NT];
+  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
+  // load side: the (offset, chunk) whose operands are being requested -- one step ahead of the MFMAs
+  v4f a0[2][2], a1[2][2];
+  int va0 = 0, va1 = 0;
+  // The three stages run on EVERY step, unconditionally (the s_waitcnt counts the compiler derives are then the same
+  // on every path: a conditional load made it wait for the loads it had just issued); after the last step they
+  // request out-of-range offsets, which cost no memory traffic.
+  int lj = 0, lc = sk_c0 - 1;       // uniform
+  int2 l_meta = make_int2(0, 0);    // s_kmeta[lj]
+  uint32_t l_voff[2] = {kAbsent, kAbsent};  // byte offset of this lane's row (+ 16 kk) for the two groups
+  const uint32_t off_lane = (uint32_t)(wave * 32 + i) * 4;
+  auto stage_meta = [&]() {  // advance to the next (offset, chunk); its look-up
+    ++lc;
+    if (lc == nch) {
+      lc = 0;
+      ++lj;
+    }
+    lc = __builtin_amdgcn_readfirstlane(lc);  // (uniform by construction; keeps them in SGPRs)
+    lj = __builtin_amdgcn_readfirstlane(lj);
+    l_meta = s_kmeta[min(lj, KSLOTS - 1)];
+  };
+  auto stage_b = [&](bool live) {  // weights of (lj, lc); this lane's rows of the offset table
+    const int krow = __builtin_amdgcn_readfirstlane(l_meta.x) & 31;
+    const uint32_t wofs = (uint32_t)__builtin_amdgcn_readfirstlane(l_meta.y);
+    const char* row = reinterpret_cast<const char*>(&s_off[0][0]) + min(krow, KSLOTS - 1) * (TM * 4) + off_lane;
+    l_voff[0] = *reinterpret_cast<const uint32_t*>(row);
+    l_voff[1] = *reinterpret_cast<const uint32_t*>(row + 64);
+    const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wofs + (uint32_t)lc * b_chunk_bytes));
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+      breg[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(wr, live ? bvo[q] : kAbsent, live ? soff : 0u, 0));
+  };
+  auto stage_a = [&](v4f (&dst)[2][2], bool live) -> int {  // gathers of (lj, lc)
+    const uint32_t v0 = live ? l_voff[0] : kAbsent, v1 = live ? l_voff[1] : kAbsent;
+    const int va = (__any(v0 != kAbsent) ? 1 : 0) | (__any(v1 != kAbsent) ? 2 : 0);
+    const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(lc * (kKC * 4));
+    const uint32_t o0 = v0 + 16 * kk, o1 = v1 + 16 * kk;  // absent stays out of range
+    dst[0][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0, soff, 0));
+    dst[1][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1, soff, 0));
+    dst[0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0 + 64, soff, 0));
+    dst[1][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1 + 64, soff, 0));
+    return PCMI_ABLATE == 1 ? 3 : va;
+  };
+
+  PROF_T(pt_pro);
+  PROF_ADD(0, pt_pro - pt_piece);
+  if (nsteps > 0) {
+    stage_meta();
+    stage_b(true);
+    va0 = stage_a(a0, true);
+    store_b(0);
+    __syncthreads();
+    PROF_T(pt_fill);
+    PROF_ADD(1, pt_fill - pt_pro);
+    // one chunk step on operand set `cur`, requesting the next one into `nxt` (two sets, swapped every step: no copies,
+    // and the wait for a gather sits at its first use)
+    auto do_step = [&](int step, v4f (&cur)[2][2], int va_cur, v4f (&nxt)[2][2], int& va_nxt) {
+      const bool more = step + 1 < nsteps;
+      PROF_T(pt1);
+      PROF_ADD(7, (unsigned long long)(((va_cur & 1) + ((va_cur >> 1) & 1)) * 8 * CTN));
+      if constexpr (SK && PCMI_ABLATE != 10) {
+        // issue priority falls with the workgroup's progress through its (equal) share of units: the four workgroups
+        // of a CU otherwise finish staggered (oldest first), and the last ones run with a half-empty matrix pipe
+        const int qtr = __builtin_amdgcn_readfirstlane(((sk_done + step) * 4) / max(sk_total, 1));
+        if (qtr != prio_qtr) {
+          prio_qtr = qtr;
+          if (qtr <= 0) __builtin_amdgcn_s_setprio(3);
+          else if (qtr == 1) __builtin_amdgcn_s_setprio(2);
+          else if (qtr == 2) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      const float* sb = s_f + (step & 1) * (kKC * LDB) + i + (4 * kk) * LDB;
+      constexpr int QN = 8, PF = 2;
+      float bf[PF][CTN];
+      if (va_cur) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+          for (int ct = 0; ct < CTN; ++ct) bf[q][ct] = sb[(16 * (q >> 2) + (q & 3)) * LDB + ct * 16];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool g0 = (va_cur & 1) != 0, g1 = (va_cur & 2) != 0;
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        const float av0 = cur[0][q >> 2][q & 3], av1 = cur[1][q >> 2][q & 3];
+        if (g0) {
+#pragma unroll
+          for (int ct = 0; ct < CTN; ++ct)
+            acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bf[q % PF][ct], acc[0][ct], 0, 0, 0);
+        }
+        if (g1) {
+#pragma unroll
+          for (int ct = 0; ct < CTN; ++ct)
+            acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bf[q % PF][ct], acc[1][ct], 0, 0, 0);
+        }
+        if (va_cur && q + PF < QN) {
+          const int qq = q + PF;
+#pragma unroll
+          for (int ct = 0; ct < CTN; ++ct) bf[q % PF][ct] = sb[(16 * (qq >> 2) + (qq & 3)) * LDB + ct * 16];
+        }
+        // the next step's operands, requested in the shadow of this step's MFMAs
+        if (q == 0) stage_meta();
+        if (q == 1) stage_b(more);
+        if (q == 2) va_nxt = stage_a(nxt, more);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      PROF_T(pt2);
+      PROF_ADD(3, pt2 - pt1);
+      PROF_ADD(4, 1);
+      if (more) store_b((step + 1) & 1);
+      __syncthreads();
+      PROF_T(pt3);
+      PROF_ADD(5, pt3 - pt2);
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+      do_step(step, a0, va0, a1, va1);
+      if (step + 1 < nsteps) do_step(step + 1, a1, va1, a0, va0);
+    }
+  }
+
+  // ---- epilogue: D[row = 4 kk + r][col = i] of every 16x16 tile --------------------------------------------------
+  if (SK && !sk_whole) {
+    float* pp = a.sk_part + ((int64_t)(2 * sk_g + (sk_first ? 0 : 1)) * TM + wave * 32) * a.N + n0 + i;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = g * 16 + 4 * kk + r;
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) pp[(int64_t)rl * a.N + ct * 16] = acc[g][ct][r];
+      }
+  } else {
+    float* outp = a.out + (int64_t)blockIdx.z * a.split_stride;
+    float bv[CTN];
+#pragma unroll
+    for (int ct = 0; ct < CTN; ++ct) bv[ct] = a.bias ? a.bias[n0 + ct * 16 + i] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int32_t orow = s_orow[wave * 32 + g * 16 + 4 * kk + r];
+        if (orow >= 0) {
+          float* op = outp + (int64_t)orow * a.out_ld + n0 + i;
+          if (a.accumulate) {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] += acc[g][ct][r] + bv[ct];
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] = acc[g][ct][r] + bv[ct];
+          }
+        }
+      }
+  }
+  PROF_T(pt_end);
+  PROF_ADD(6, pt_end - pt_piece);
+#if PCMI_ABLATE == 9
+  if (!SK || sk_next_u >= sk_u1) {
+    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
+      unsigned long long* o = g_conv16_prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12;
+      prof[11] = __builtin_readcyclecounter();
+      for (int q = 0; q < 12; ++q) o[q] = prof[q];
+    }
+  }
+#endif
+  if constexpr (!SK) {
+    break;
+  } else {
+    sk_u = sk_next_u;
+    ++sk_tile;
+    sk_first = false;
+    sk_done += nsteps;
+    if (sk_u >= sk_u1) break;
+    __syncthreads();  // s_off / s_orow / the staging area are rewritten by the next piece
+  }
+  }  // for (;;)
+}
+
 // Sums the pieces of the tiles that the SK launch split between workgroups (see spconv_mfma_kernel) into the
 // output rows, in workgroup order.  One workgroup per tile; tiles written whole by one workgroup are skipped.
 __global__ __launch_bounds__(256) void sk_fixup_kernel(const float* __restrict__ part, const int32_t* __restrict__ pref,
                                                        int n_tiles, int G, const int32_t* __restrict__ perm, int64_t n_rows,
                                                        int N, const float* __restrict__ bias, float* __restrict__ out,
-                                                       int64_t out_ld, int accumulate) {
+                                                       int64_t out_ld, int accumulate, int sub) {
   constexpr int TM = 128;
   const int tile = blockIdx.x;
-  const int U = pref[n_tiles], per = (U + G - 1) / G;
-  const int u0 = pref[tile], u1 = pref[tile + 1];
+  // sub: shares counted in sub-steps of a unit (spconv16p_kernel: C / 32 chunk steps), 1 = whole units
+  const int U = pref[n_tiles] * sub, per = (U + G - 1) / G;
+  const int u0 = pref[tile] * sub, u1 = pref[tile + 1] * sub;
   if (u1 <= u0) return;
   const int g_first = u0 / per, g_last = (u1 - 1) / per;
   if (g_first == g_last) return;  // one workgroup had the whole tile and wrote it itself
@@ -897,14 +1302,32 @@ static size_t sk_partial_bytes(int64_t rows, int N, int K) {
 // The 16-row kernel takes the 128-row tiles of levels with at least PCMI_CONV16 rows (default 8192; 0 = never, 1 =
 // always).  Measured (scripts/kbench.py): level 2 (20k rows) 3-5 % faster, level 1 equal, the <= 5k-row levels
 // 3-9 % slower (their NT = 1 / offset-split launches are latency-, not matrix-bound).
-static bool conv16_enabled(int64_t n_rows) {
+static bool conv16_enabled(int64_t n_rows, int64_t x_bytes) {
   const char* e = getenv("PCMI_CONV16");
   const int64_t min_rows = e ? atoll(e) : 8192;
-  return min_rows > 0 && n_rows >= min_rows;
+  // the pipelined form addresses the gathered operand with 32-bit byte offsets (absent = 2^31)
+  return min_rows > 0 && n_rows >= min_rows && x_bytes <= 0x7FFFFF00ll;
+}
+
+// PCMI_CONV16_PIPE=0: the unpipelined spconv16_kernel (A/B and the parity test of the two forms)
+static bool conv16_pipelined() {
+  const char* e = getenv("PCMI_CONV16_PIPE");
+  return !e || atoi(e) != 0;
 }
 
 template <bool WT, bool SK>
 static int launch16(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  if (conv16_pipelined()) {
+    switch (NT) {
+      case 1: spconv16p_kernel<1, WT, SK><<<grid, 256, 0, st>>>(a); break;
+      case 2: spconv16p_kernel<2, WT, SK><<<grid, 256, 0, st>>>(a); break;
+      case 3: spconv16p_kernel<3, WT, SK><<<grid, 256, 0, st>>>(a); break;
+      case 4: spconv16p_kernel<4, WT, SK><<<grid, 256, 0, st>>>(a); break;
+      default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
+    }
+    PCMI_LAUNCH_CHECK();
+    return PCMI_OK;
+  }
   switch (NT) {
     case 1: spconv16_kernel<1, WT, SK><<<grid, 256, 0, st>>>(a); break;
     case 2: spconv16_kernel<2, WT, SK><<<grid, 256, 0, st>>>(a); break;
@@ -1009,7 +1432,7 @@ static size_t partial_bytes(int64_t rows, int N, int K) {
 }
 
 // One gathered GEMM:  out[rows, N] = sum_k x[idx_k(rows)] @ B_k
-static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int cin, int cout,
+static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, const float* w, int cin, int cout,
                         bool w_transposed, int N, const pcmi_kmap_t* map, bool pair_mode,
                         bool swap_pairs, const int32_t* wsel, const float* bias, float* out,
                         int64_t out_ld, int64_t n_rows, int accumulate, void* ws, size_t ws_bytes,
@@ -1073,7 +1496,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
       map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64) {
-    const int G = conv16_enabled(n_rows) ? sk_workgroups(p.NT) : sk_workgroups(4);
+    const int G = conv16_enabled(n_rows, x_rows * x_ld * 4) ? sk_workgroups(p.NT) : sk_workgroups(4);
     const size_t need = sk_partial_bytes(n_rows, N, a.K);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
     a.sk_mask = map->tile_mask;
@@ -1082,13 +1505,14 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
     a.sk_part = (float*)ws;
     dim3 grid((unsigned)G, (unsigned)(N / (32 * p.NT)), 1);
     int rc;
-    if (conv16_enabled(n_rows))
+    if (conv16_enabled(n_rows, x_rows * x_ld * 4))
       rc = w_transposed ? launch16<true, true>(p.NT, a, grid, st) : launch16<false, true>(p.NT, a, grid, st);
     else
       rc = w_transposed ? launch_sk<true>(p.NT, a, grid, st) : launch_sk<false>(p.NT, a, grid, st);
     if (rc) return rc;
+    const int sub = (conv16_enabled(n_rows, x_rows * x_ld * 4) && conv16_pipelined()) ? C / kKC : 1;
     sk_fixup_kernel<<<dim3((unsigned)a.sk_tiles), 256, 0, st>>>(a.sk_part, a.sk_pref, a.sk_tiles, G, a.perm, n_rows, N, bias,
-                                                              out, out_ld, accumulate);
+                                                              out, out_ld, accumulate, sub);
     PCMI_LAUNCH_CHECK();
     return PCMI_OK;
   }
@@ -1109,7 +1533,7 @@ static int run_gathered(const float* x, int64_t x_ld, int C, const float* w, int
   }
   dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
   int rc;
-  if (p.RW == 4 && conv16_enabled(n_rows)) {
+  if (p.RW == 4 && conv16_enabled(n_rows, x_rows * x_ld * 4)) {
     rc = w_transposed ? launch16<true, false>(p.NT, a, grid, st) : launch16<false, false>(p.NT, a, grid, st);
   } else if (p.RW == 4 && (w_transposed ? launch_deep<true>(p.NT, a, grid, st) : launch_deep<false>(p.NT, a, grid, st))) {
     rc = PCMI_OK;
@@ -1167,7 +1591,7 @@ int spconv_forward_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, co
   // rows = output rows.  transposed conv over a stride-2 map: one offset per fine row -> pair mode
   const bool pair_mode = map && transpose;
   PCMI_REQUIRE(!(map && transpose && map->stride != 2), PCMI_ERR_UNSUPPORTED, "spconv_fwd: transposed conv needs a stride-2 map");
-  return run_gathered(in, in_ld, cin, weight, cin, cout, false, cout, map, pair_mode, false, nullptr, bias, out,
+  return run_gathered(in, in_ld, n_in, cin, weight, cin, cout, false, cout, map, pair_mode, false, nullptr, bias, out,
                       out_ld, n_out, accumulate, ws, ws_bytes, st);
 }
 
@@ -1177,7 +1601,7 @@ int spconv_backward_data_m32(const float* gout, int64_t gout_ld, int64_t n_out, 
   PCMI_REQUIRE(gout && weight && gin && cin >= 8 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_data: bad argument (cin=%d)", cin);
   if (!map) {
     PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_data: dense path needs n_in == n_out");
-    return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, nullptr, false, false, nullptr, nullptr,
+    return run_gathered(gout, gout_ld, n_out, cout, weight, cin, cout, true, cin, nullptr, false, false, nullptr, nullptr,
                         gin, gin_ld, n_in, accumulate, ws, ws_bytes, st);
   }
   const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
@@ -1185,16 +1609,16 @@ int spconv_backward_data_m32(const float* gout, int64_t gout_ld, int64_t n_out, 
   if (map->stride == 1) {
     // gin[i] = sum_k gout[nbr[k][i]] @ W[mirror(k)]^T  (in and out rows coincide)
     PCMI_REQUIRE(!transpose, PCMI_ERR_UNSUPPORTED, "spconv_bwd_data: transposed stride-1 conv is not on the hot path");
-    return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, false, false, map->mirror, nullptr,
+    return run_gathered(gout, gout_ld, n_out, cout, weight, cin, cout, true, cin, map, false, false, map->mirror, nullptr,
                         gin, gin_ld, n_in, accumulate, ws, ws_bytes, st);
   }
   if (!transpose) {
     // strided conv: every fine (input) row has exactly one (coarse row, k): pair mode, rows = fine
-    return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, true, false, nullptr, nullptr, gin,
+    return run_gathered(gout, gout_ld, n_out, cout, weight, cin, cout, true, cin, map, true, false, nullptr, nullptr, gin,
                         gin_ld, n_in, accumulate, ws, ws_bytes, st);
   }
   // transposed conv: gin (coarse) gathers its children: nbr table, rows = coarse
-  return run_gathered(gout, gout_ld, cout, weight, cin, cout, true, cin, map, false, false, nullptr, nullptr, gin,
+  return run_gathered(gout, gout_ld, n_out, cout, weight, cin, cout, true, cin, map, false, false, nullptr, nullptr, gin,
                       gin_ld, n_in, accumulate, ws, ws_bytes, st);
 }
 
@@ -1216,6 +1640,20 @@ int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int 
                          void* ws, size_t ws_bytes, pcmi_stream_t stream) {
   return spconv_backward_data(gout, gout_ld, n_out, cout, weight, cin, map, transpose, gin, gin_ld, n_in, 0, ws,
                               ws_bytes, as_stream(stream));
+}
+
+#if PCMI_ABLATE == 9
+int pcmi_debug_conv_prof(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv16_prof), sizeof(unsigned long long) * 4096 * 12) == hipSuccess ? PCMI_OK : PCMI_ERR_HIP;
+}
+#endif
+
+// diagnostic (scripts/): resident workgroups per CU of the level-1 kernels as the runtime computes them
+int pcmi_debug_conv_occupancy(int* conv16_nt3, int* conv16_nt4, int* mfma_nt3_sk) {
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(conv16_nt3, spconv16_kernel<3, false, true>, 256, 0);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(conv16_nt4, spconv16_kernel<4, false, true>, 256, 0);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(mfma_nt3_sk, spconv_mfma_kernel<3, 4, false, false, true>, 256, 0);
+  return e == hipSuccess ? PCMI_OK : PCMI_ERR_HIP;
 }
 
 }  // extern "C"

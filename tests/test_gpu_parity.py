@@ -926,3 +926,36 @@ def test_conv16_matches_32row_kernel(ME, size, cin, cout, monkeypatch):
   monkeypatch.delenv("PCMI_CONV16")
   assert_close(res["1"][0], res["0"][0], 1e-5, "16-row forward")
   assert_close(res["1"][1], res["0"][1], 1e-5, "16-row backward-data")
+
+
+@pytest.mark.parametrize("size,cin,cout", [("small", 64, 96), ("mid", 128, 32), ("large", 96, 96), ("large", 64, 128)])
+def test_conv16_pipelined_matches_unpipelined(ME, size, cin, cout, monkeypatch):
+  """spconv16p_kernel (next step's buffer loads issued from inside the MFMA stream; PCMI_CONV16_PIPE, default on)
+  against spconv16_kernel: same operands, same accumulation order -> identical bits on whole tiles, forward and
+  backward-data; 1e-5 under the unit-balanced launch (different split points)."""
+  from pointcontrast_amd import functional as PF
+  C = _coords(size)
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  torch.manual_seed(4)
+  W = (torch.randn(27, cin, cout, device=DEV) / (cin * 27) ** 0.5).requires_grad_(True)
+  b = torch.randn(cout, device=DEV)
+  g = torch.randn(len(C), cout, device=DEV)
+  monkeypatch.setenv("PCMI_CONV16", "1")
+  for sk in ("16", "0"):
+    monkeypatch.setenv("PCMI_SPCONV_STREAMK", sk)
+    res = {}
+    for mode in ("0", "1"):
+      monkeypatch.setenv("PCMI_CONV16_PIPE", mode)
+      x = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
+      y = PF.SparseConvFunction.apply(x, W, b, m, False, len(C), cm)
+      y.backward(g)
+      torch.cuda.synchronize()
+      res[mode] = (y.detach().clone(), x.grad.clone())
+    if sk == "0":
+      assert torch.equal(res["1"][0], res["0"][0]), "forward"
+      assert torch.equal(res["1"][1], res["0"][1]), "backward-data"
+    else:  # the unit-balanced launch of the pipelined form cuts its shares at chunk steps, not at offsets: same sums, other grouping
+      assert_close(res["1"][0], res["0"][0], 1e-5, "forward, unit-balanced")
+      assert_close(res["1"][1], res["0"][1], 1e-5, "backward-data, unit-balanced")
