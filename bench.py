@@ -298,6 +298,8 @@ def main():
   np.random.seed(rank)
   cls = ddp_trainer.PointNCELossTrainer if args.loss == "nce" else ddp_trainer.HardestContrastiveLossTrainer
   trainer = cls(cfg, loader)
+  if cfg.misc.get("gpu_profile", False) and trainer.engine is not None:
+    trainer.engine.pair_marks = []
   it = iter(loader)
   timers = [AverageMeter(), Timer(), Timer()]
 
@@ -345,6 +347,8 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine, "final_loss": round(loss_val, 5),
                    "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),
+                   **({"forward_pair_ms": trainer.engine.pair_marks_ms(skip=args.warmup)}
+                      if getattr(trainer.engine, "pair_marks", None) else {}),
                    **({"host_phase_ms_per_step": {k: round(v / (args.steps + args.warmup), 3) for k, v in trainer.host_ms.items()}}
                       if trainer.host_ms else {}),
                    "conv_gflop_per_forward": round(flops * 1e-9, 2), "conv_algo_gb_per_forward": round(byts * 1e-9, 3),

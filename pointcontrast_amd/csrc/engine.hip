@@ -131,7 +131,7 @@ struct pcmi_net {
   // writes its parameter gradients to `grads_peer` (added to the caller's buffer bucket by bucket by pass 0).
   hipStream_t side[2] = {nullptr, nullptr};
   hipStream_t chain1 = nullptr;  // chain stream of pass 1 in pcmi_net_backward_pair
-  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_fork = nullptr;
+  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_switch = nullptr;
   pcmi::DevBuf ws_side[2];
   pcmi::DevBuf grads_peer;
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
@@ -144,6 +144,7 @@ struct pcmi_net {
     }
     if (chain1) (void)hipStreamDestroy(chain1);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_switch) (void)hipEventDestroy(ev_switch);
   }
 };
 
@@ -235,70 +236,48 @@ static int ensure_streams(pcmi_net& n) {
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
   }
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_switch, hipEventDisableTiming));
   return PCMI_OK;
 }
 
-static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params, float* grads,
-                        const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready, void* ready_ctx) {
-  hipStream_t st = job.st;
-  PassState& ps = n.passes[job.pass];
-  const float* d_out = job.d_out;
-  const int64_t d_ld = job.d_ld;
-  const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
-  if (n_buckets < 0 || !bucket_lo_host) n_buckets = 0;
-  // gradient arena of this pass (its own: the two passes of a pair run concurrently)
-  ps.grad_off.assign(n_t, 0);
-  size_t off = 0;
-  int max_c = 4;
-  for (int t = 0; t < n_t; ++t) {
-    max_c = std::max(max_c, n.tensors[t].channels);
-    if (n.tensors[t].parent >= 0 || t == n.input_tensor || t == n.output_tensor) continue;
-    ps.grad_off[t] = off;
-    off += align_up((size_t)ps.rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
-  }
-  int rc = ps.grad.reserve(off, st);
-  if (rc) return rc;
-  rc = ps.small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
-  if (rc) return rc;
-  float* scratch_g = (float*)ps.small.p;
-  const bool deferred = job.role == BackwardJob::DEFERRED, primary = job.role == BackwardJob::PRIMARY;
-  PassState* peer = primary ? &n.passes[1] : nullptr;
-  // where this pass's parameter gradients go: DEFERRED stores into the peer buffer, the others accumulate
-  float* gdst = deferred ? (float*)n.grads_peer.p : grads;
-  const int gacc = deferred ? 0 : 1;
-  if (deferred)
-    while ((int)ps.bucket_ev.size() < n_buckets + 1) {
-      hipEvent_t e;
-      PCMI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      ps.bucket_ev.push_back(e);
-    }
-  // ---- weight-gradient stream ------------------------------------------------------------------------
-  static const bool side_enabled = [] {
-    const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
-    return !(e && e[0] == '0');
-  }();
-  const int sidx = deferred ? 1 : 0;
-  hipStream_t wst = st;
-  DevBuf* wws = &ps.ws;
-  if (side_enabled || job.role != BackwardJob::SOLO) {
-    rc = ensure_streams(n);
-    if (rc) return rc;
-    rc = n.ws_side[sidx].reserve(ps.ws.cap, n.side[sidx]);
-    if (rc) return rc;
-    wst = n.side[sidx];
-    wws = &n.ws_side[sidx];
-  }
-  bool side_pending = false;
-  auto join_side = [&]() -> int {  // `st` continues only after the weight gradients enqueued so far
+// One pass's backward as an object the caller advances op by op: pcmi_net_backward_pair interleaves the ENQUEUE of its
+// two passes (op i of pass 1, op i of pass 0, op i-1 of pass 1, ...), so that both chains are present on the GPU at
+// the same time -- enqueueing one whole pass after the other leaves the second chain ~10 ms of host time behind the
+// first, i.e. no overlap at all.
+struct BackwardRun {
+  pcmi_net& n;
+  BackwardJob job;
+  const float* params;
+  float* grads;
+  const int64_t* bucket_lo_host;
+  int n_buckets;
+  pcmi_ready_fn ready;
+  void* ready_ctx;
+  // set by begin()
+  hipStream_t st = nullptr, wst = nullptr;
+  PassState* ps = nullptr;
+  PassState* peer = nullptr;
+  DevBuf* wws = nullptr;
+  float* scratch_g = nullptr;
+  float* gdst = nullptr;
+  int gacc = 1, sidx = 0;
+  bool deferred = false, primary = false, side_pending = false;
+  std::vector<int> bucket_last;
+
+  BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
+              void* rc)
+      : n(net), job(j), params(prm), grads(g), bucket_lo_host(blo), n_buckets(nb), ready(r), ready_ctx(rc) {}
+
+  int join_side() {  // `st` continues only after the weight gradients enqueued so far
     if (!side_pending) return PCMI_OK;
     PCMI_HIP_CHECK(hipEventRecord(n.ev_side[sidx], wst));
     PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[sidx], 0));
     side_pending = false;
     return PCMI_OK;
-  };
-  auto bucket_hi = [&](int q) { return q + 1 < n_buckets ? bucket_lo_host[q + 1] : n.param_extent; };
+  }
+  int64_t bucket_hi(int q) const { return q + 1 < n_buckets ? bucket_lo_host[q + 1] : n.param_extent; }
   // everything the DEFERRED peer contributes to [lo, hi) is added to `grads` (q: the peer's boundary event)
-  auto absorb_peer = [&](int q, int64_t lo, int64_t hi) -> int {
+  int absorb_peer(int q, int64_t lo, int64_t hi) {
     int r = join_side();
     if (r) return r;
     PCMI_HIP_CHECK(hipStreamWaitEvent(st, peer->bucket_ev[q], 0));
@@ -310,29 +289,108 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
       PCMI_LAUNCH_CHECK();
     }
     return PCMI_OK;
-  };
-  // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
-  std::vector<int> bucket_last(n_buckets, -1);
-  auto bucket_of = [&](int64_t offp) {
+  }
+  int bucket_of(int64_t offp) const {
     int b = 0;
     for (int q = 0; q < n_buckets; ++q)
       if (offp >= bucket_lo_host[q]) b = q;
     return b;
-  };
-  for (int i = n_ops - 1; i >= 0 && n_buckets > 0; --i) {
-    const auto& op = n.ops[i];
-    if (op.type == PCMI_OP_L2NORM) continue;
-    bucket_last[bucket_of(op.w_off)] = i;
-    if (op.type == PCMI_OP_BN || op.has_bias) bucket_last[bucket_of(op.b_off)] = i;
   }
-  for (int i = n_ops - 1; i >= 0; --i) {
+
+  int begin() {
+    st = job.st;
+    ps = &n.passes[job.pass];
+    const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
+    if (n_buckets < 0 || !bucket_lo_host) n_buckets = 0;
+    // gradient arena of this pass (its own: the two passes of a pair run concurrently)
+    ps->grad_off.assign(n_t, 0);
+    size_t off = 0;
+    int max_c = 4;
+    for (int t = 0; t < n_t; ++t) {
+      max_c = std::max(max_c, n.tensors[t].channels);
+      if (n.tensors[t].parent >= 0 || t == n.input_tensor || t == n.output_tensor) continue;
+      ps->grad_off[t] = off;
+      off += align_up((size_t)ps->rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
+    }
+    int rc = ps->grad.reserve(off, st);
+    if (rc) return rc;
+    rc = ps->small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
+    if (rc) return rc;
+    scratch_g = (float*)ps->small.p;
+    deferred = job.role == BackwardJob::DEFERRED;
+    primary = job.role == BackwardJob::PRIMARY;
+    peer = primary ? &n.passes[1] : nullptr;
+    // where this pass's parameter gradients go: DEFERRED stores into the peer buffer, the others accumulate
+    gdst = deferred ? (float*)n.grads_peer.p : grads;
+    gacc = deferred ? 0 : 1;
+    if (deferred)
+      while ((int)ps->bucket_ev.size() < n_buckets + 1) {
+        hipEvent_t e;
+        PCMI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ps->bucket_ev.push_back(e);
+      }
+    // ---- weight-gradient stream ----------------------------------------------------------------------
+    static const bool side_enabled = [] {
+      const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
+      return !(e && e[0] == '0');
+    }();
+    static const bool one_side = [] {  // PCMI_PAIR_ONE_SIDE=1: both passes of a pair share weight-gradient stream 0
+      const char* e = getenv("PCMI_PAIR_ONE_SIDE");
+      return e && e[0] == '1';
+    }();
+    sidx = (deferred && !one_side) ? 1 : 0;
+    wst = st;
+    wws = &ps->ws;
+    if (side_enabled || job.role != BackwardJob::SOLO) {
+      rc = ensure_streams(n);
+      if (rc) return rc;
+      rc = n.ws_side[sidx].reserve(ps->ws.cap, n.side[sidx]);
+      if (rc) return rc;
+      wst = n.side[sidx];
+      wws = &n.ws_side[sidx];
+    }
+    side_pending = false;
+    // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
+    bucket_last.assign(n_buckets, -1);
+    for (int i = n_ops - 1; i >= 0 && n_buckets > 0; --i) {
+      const auto& op = n.ops[i];
+      if (op.type == PCMI_OP_L2NORM) continue;
+      bucket_last[bucket_of(op.w_off)] = i;
+      if (op.type == PCMI_OP_BN || op.has_bias) bucket_last[bucket_of(op.b_off)] = i;
+    }
+    return PCMI_OK;
+  }
+
+  // DEFERRED only: ops that touch a level below `own_from` run on `shared` (the PRIMARY pass's stream, i.e. in turn
+  // with its ops), the others on this pass's own chain stream.  Measured: the full-resolution kernels of two passes
+  // side by side cost more than they gain (they each want the whole chip and its L2), the latency-bound kernels of the
+  // coarse levels are the ones that overlap.
+  hipStream_t shared = nullptr, own = nullptr;
+  int own_from = 0;
+  int move_to(hipStream_t target) {
+    if (target == st) return PCMI_OK;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_switch, st));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(target, n.ev_switch, 0));
+    st = target;
+    return PCMI_OK;
+  }
+
+  int step(int i) {  // differentiate op i (called for i = n_ops - 1 ... 0)
+    const float* d_out = job.d_out;
+    const int64_t d_ld = job.d_ld;
     const auto& op = n.ops[i];
+    if (shared) {
+      const int lv = std::min(n.tensors[op.in].level, n.tensors[op.out].level);
+      const int rc0 = move_to(lv < own_from ? shared : own);
+      if (rc0) return rc0;
+    }
     const OpPlan& pl = n.plan[i];
-    const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
-    const View dy = grad_view(n, ps, op.out, d_out, d_ld);
-    const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
+    const View x = act_view(n, *ps, op.in), y = act_view(n, *ps, op.out);
+    const View dy = grad_view(n, *ps, op.out, d_out, d_ld);
+    const int64_t n_in = ps->rows[n.tensors[op.in].level], n_out = ps->rows[n.tensors[op.out].level];
+    int rc = PCMI_OK;
     if (op.type == PCMI_OP_CONV) {
-      const pcmi_kmap_t* map = ps.has_map[i] ? &ps.maps[i] : nullptr;
+      const pcmi_kmap_t* map = ps->has_map[i] ? &ps->maps[i] : nullptr;
       if (wst != st) {  // dy is complete at this point of `st` (all its consumers were differentiated before)
         PCMI_HIP_CHECK(hipEventRecord(n.ev_main[sidx], st));
         PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sidx], 0));
@@ -342,15 +400,15 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
                                   gdst + op.w_off, op.has_bias ? gdst + op.b_off : nullptr, gacc, wws->p, wws->cap, wst);
       if (rc) return rc;
       if (op.in != n.input_tensor) {
-        const View dx = grad_view(n, ps, op.in, d_out, d_ld);
+        const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
         rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
-                                  n_in, pl.acc_in, ps.ws.p, ps.ws.cap, st);
+                                  n_in, pl.acc_in, ps->ws.p, ps->ws.cap, st);
       }
     } else if (op.type == PCMI_OP_BN) {
-      const View dx = grad_view(n, ps, op.in, d_out, d_ld);
+      const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
       View dr = {nullptr, 0};
-      if (op.in2 >= 0) dr = grad_view(n, ps, op.in2, d_out, d_ld);
-      const float* stats = (const float*)(ps.act.p + ps.stat_off[i]);
+      if (op.in2 >= 0) dr = grad_view(n, *ps, op.in2, d_out, d_ld);
+      const float* stats = (const float*)(ps->act.p + ps->stat_off[i]);
       float* dgamma = scratch_g;
       float* dbeta = scratch_g + op.cout;
       float* acc_g = grads + op.w_off;
@@ -361,11 +419,11 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
         acc_g = acc_b = nullptr;
       }
       rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats,
-                       stats + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps.ws.p,
-                       ps.ws.cap, st);
+                       stats + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps->ws.p,
+                       ps->ws.cap, st);
     } else {
-      const View dx = grad_view(n, ps, op.in, d_out, d_ld);
-      rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps.act.p + ps.stat_off[i]), n_in, op.cout, dx.p, dx.ld,
+      const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
+      rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps->act.p + ps->stat_off[i]), n_in, op.cout, dx.p, dx.ld,
                            (pcmi_stream_t)st);
     }
     if (rc) return rc;
@@ -374,26 +432,42 @@ static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params
         if (deferred) {  // everything this pass contributes to bucket b is in the peer buffer behind this event
           rc = join_side();
           if (rc) return rc;
-          PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[b], st));
+          PCMI_HIP_CHECK(hipEventRecord(ps->bucket_ev[b], st));
         } else {
           rc = primary ? absorb_peer(b, bucket_lo_host[b], bucket_hi(b)) : join_side();
           if (rc) return rc;
           if (ready) ready(ready_ctx, b);
         }
       }
+    return PCMI_OK;
   }
-  rc = join_side();
-  if (rc) return rc;
-  if (deferred) {
-    PCMI_HIP_CHECK(hipEventRecord(ps.bucket_ev[n_buckets], st));
-  } else if (primary) {
-    // no buckets: the whole peer buffer at once; with buckets: only ordering (the peer is done with its arenas)
-    rc = n_buckets == 0 ? absorb_peer(0, 0, n.param_extent) : absorb_peer(n_buckets, 0, 0);
+
+  int end() {
+    int rc = join_side();
     if (rc) return rc;
-    peer->valid = false;
+    if (shared) {
+      rc = move_to(own);  // the boundary events below belong to the pass's own stream
+      if (rc) return rc;
+    }
+    if (deferred) {
+      PCMI_HIP_CHECK(hipEventRecord(ps->bucket_ev[n_buckets], st));
+    } else if (primary) {
+      // no buckets: the whole peer buffer at once; with buckets: only ordering (the peer is done with its arenas)
+      rc = n_buckets == 0 ? absorb_peer(0, 0, n.param_extent) : absorb_peer(n_buckets, 0, 0);
+      if (rc) return rc;
+      peer->valid = false;
+    }
+    if (!deferred) ps->valid = false;
+    return PCMI_OK;
   }
-  if (!deferred) ps.valid = false;
-  return PCMI_OK;
+};
+
+static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params, float* grads,
+                        const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready, void* ready_ctx) {
+  BackwardRun r(n, job, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
+  int rc = r.begin();
+  for (int i = (int)n.ops.size() - 1; i >= 0 && !rc; --i) rc = r.step(i);
+  return rc ? rc : r.end();
 }
 
 }  // namespace pcmi
@@ -669,15 +743,36 @@ int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, 
   j1.d_ld = d_ld1;
   j1.st = n.chain1;
   j1.role = BackwardJob::DEFERRED;
-  rc = run_backward(n, j1, params, grads, bucket_lo_host, n_buckets, nullptr, nullptr);
-  if (rc) return rc;
   BackwardJob j0;
   j0.pass = 0;
   j0.d_out = d_out0;
   j0.d_ld = d_ld0;
   j0.st = st;
   j0.role = BackwardJob::PRIMARY;
-  return run_backward(n, j0, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
+  BackwardRun r1(n, j1, params, grads, bucket_lo_host, n_buckets, nullptr, nullptr);
+  BackwardRun r0(n, j0, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
+  rc = r1.begin();
+  if (rc) return rc;
+  rc = r0.begin();
+  if (rc) return rc;
+  static const int own_from = [] {  // PCMI_PAIR_OWN_FROM: first level whose ops pass 1 runs on its own stream (0 = all)
+    const char* e = getenv("PCMI_PAIR_OWN_FROM");
+    return e ? atoi(e) : 1;
+  }();
+  if (own_from > 0) {
+    r1.shared = st;
+    r1.own = n.chain1;
+    r1.own_from = own_from;
+  }
+  // op by op, pass 1 first: its bucket events are recorded before pass 0 waits for them
+  for (int i = (int)n.ops.size() - 1; i >= 0; --i) {
+    rc = r1.step(i);
+    if (rc) return rc;
+    rc = r0.step(i);
+    if (rc) return rc;
+  }
+  rc = r1.end();
+  return rc ? rc : r0.end();
 }
 
 }  // extern "C"

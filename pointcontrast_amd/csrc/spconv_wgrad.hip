@@ -81,6 +81,43 @@ struct VecLoad<4> {
   }
 };
 
+// V consecutive floats through a raw buffer load: an offset >= 2^31 (kAbsentRow) is out of range and returns zeros.
+// (The results are taken over with `auto` + memcpy: assigning the b64 / b96 builtins to an int ext-vector compiled to
+// a ONE-dword load with the first element broadcast.)
+constexpr uint32_t kAbsentRow = 0x80000000u;
+template <int V>
+struct BufLoad;
+template <>
+struct BufLoad<1> {
+  static __device__ inline void ld(__amdgpu_buffer_rsrc_t r, uint32_t off, float* v) {
+    v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  }
+};
+template <>
+struct BufLoad<2> {
+  static __device__ inline void ld(__amdgpu_buffer_rsrc_t r, uint32_t off, float* v) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    static_assert(sizeof(t) == 8, "b64");
+    __builtin_memcpy(v, &t, 8);
+  }
+};
+template <>
+struct BufLoad<3> {
+  static __device__ inline void ld(__amdgpu_buffer_rsrc_t r, uint32_t off, float* v) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b96(r, off, 0, 0);
+    static_assert(sizeof(t) >= 12, "b96");
+    __builtin_memcpy(v, &t, 12);
+  }
+};
+template <>
+struct BufLoad<4> {
+  static __device__ inline void ld(__amdgpu_buffer_rsrc_t r, uint32_t off, float* v) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    static_assert(sizeof(t) == 16, "b128");
+    __builtin_memcpy(v, &t, 16);
+  }
+};
+
 // chunk c of the launch -> (offset k, first pair, last pair); first_chunk / n_chunks: the chunks of that offset
 __device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int chunk, int64_t c,
                                     int* k_out, int64_t* pb, int64_t* pe, int64_t* first_chunk = nullptr,
@@ -112,24 +149,71 @@ __device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int c
   *pb = *pe = 0;
 }
 
-template <int CT, int NT, bool IDX>
+#ifndef PCMI_ABLATE
+#define PCMI_ABLATE 0
+#endif
+#if PCMI_ABLATE == 9  // per-wave cycle accounting (scripts/wgrad_prof.py)
+__device__ unsigned long long g_wgrad_prof[4096 * 8];
+#define WPROF(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define WPROF(v)
+#endif
+
+// locate_chunk by one wave: lane k reads the bounds of offset k, the chunk counts are scanned across the lanes -- one
+// memory latency instead of up to K dependent ones (measured: 6 us of a 25 us launch at the coarse levels)
+__device__ inline void locate_chunk_wave(const int64_t* offs, int K, int64_t M, int chunk, int64_t c, int lane,
+                                         int64_t* desc /* k, pb, pe, first_chunk, n_chunks */) {
+  if (!offs) {
+    if (lane == 0) {
+      desc[0] = 0;
+      desc[1] = c * chunk;
+      desc[2] = min(desc[1] + (int64_t)chunk, M);
+      desc[3] = 0;
+      desc[4] = (M + chunk - 1) / chunk;
+    }
+    return;
+  }
+  const int64_t b = lane <= K ? offs[lane] : 0;
+  const int64_t e = __shfl_down(b, 1, 64);
+  const int64_t nc = lane < K ? (e - b + chunk - 1) / chunk : 0;
+  int64_t incl = nc;  // inclusive scan over the lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t v = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += v;
+  }
+  const unsigned long long hit = __ballot(lane < K && c < incl);
+  if (hit == 0) {
+    if (lane == 0) {
+      desc[0] = -1;
+      desc[1] = desc[2] = desc[3] = desc[4] = 0;
+    }
+    return;
+  }
+  const int k = __ffsll((long long)hit) - 1;
+  if (lane == k) {
+    const int64_t first = incl - nc, j = c - first;
+    desc[0] = k;
+    desc[1] = b + j * chunk;
+    desc[2] = min(desc[1] + (int64_t)chunk, e);
+    desc[3] = first;
+    desc[4] = nc;
+  }
+}
+
+template <int CT, int NT, bool IDX, bool BUF>
 // min 2 waves/SIMD keeps the 9 accumulator tiles in VGPRs (198 registers); unbounded, hipcc used 190 + 144 AGPRs = 1 wave/SIMD
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   __shared__ float s_red[32 * CT][32 * NT + 1];
-  __shared__ int64_t s_desc[5];
+  __shared__ int64_t s_desc[6];
   __shared__ unsigned s_last;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int c0 = blockIdx.y * 32 * CT, n0 = blockIdx.z * 32 * NT;
-  if (t == 0) {
-    int k;
-    int64_t pb, pe, fc, nc;
-    locate_chunk(a.offs, a.K, a.M, a.chunk, blockIdx.x, &k, &pb, &pe, &fc, &nc);
-    s_desc[0] = k;
-    s_desc[1] = pb;
-    s_desc[2] = pe;
-    s_desc[3] = fc;
-    s_desc[4] = nc;
+  WPROF(w_t0);
+  if (wave == 0) {
+    locate_chunk_wave(a.offs, a.K, a.M, a.chunk, blockIdx.x, lane, s_desc);
+    if (lane == 0) s_desc[5] = blockIdx.x;  // slab of this chunk
   }
   __syncthreads();
   if (s_desc[0] < 0) return;
@@ -143,87 +227,162 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[ct][nt][j] = 0.f;
 
-  const float* xcol = a.x + c0 + CT * i;
-  const float* gcol = a.g + n0 + NT * i;
-  // Each wave walks 64-pair groups (group index = wave, wave+4, ...); one group is 32 MFMA contraction steps of two
-  // pairs.  The operand rows of step s+D are requested while step s multiplies (register ring of D steps, running on
-  // into the next group): written as load -> use per step, hipcc emitted global_load -> s_waitcnt vmcnt(0) -> MFMAs,
-  // the whole memory latency in front of every CT*NT MFMAs (SQ_VALU_MFMA_BUSY_CYCLES: 38 %).
-  constexpr int D = (CT * NT >= 6) ? 4 : 8;  // steps in flight: >= ~2000 cycles of matrix work (32 % D == 0)
-  float av[D][CT], bv[D][NT];
-  auto load_idx = [&](int64_t g0, int32_t& rx, int32_t& rg) {
-    const int64_t p = g0 + lane;
-    rx = IDX ? a.idx_x[p] : (int32_t)p;  // IDX is a template flag: a run-time select put an s_waitcnt vmcnt(0) here
-    rg = IDX ? a.idx_g[p] : (int32_t)p;
-  };
-  // operands of contraction step j of a FULL group: lane (i, h) takes pair 2j+h
-#define PCMI_WGRAD_LOAD(J, RX, RG)                                                            \
-  {                                                                                           \
-    const int32_t ix0 = __builtin_amdgcn_readlane(RX, 2 * (J)), ix1 = __builtin_amdgcn_readlane(RX, 2 * (J) + 1); \
-    const int32_t ig0 = __builtin_amdgcn_readlane(RG, 2 * (J)), ig1 = __builtin_amdgcn_readlane(RG, 2 * (J) + 1); \
-    VecLoad<CT>::ld(xcol + (int64_t)(h ? ix1 : ix0) * a.x_ld, av[(J) % D]);                   \
-    VecLoad<NT>::ld(gcol + (int64_t)(h ? ig1 : ig0) * a.g_ld, bv[(J) % D]);                   \
-  }
-  int64_t g0 = pb + (int64_t)wave * 64;
-  int32_t rx = 0, rg = 0, rxn = 0, rgn = 0;
-  bool primed = false;  // ring holds steps 0..D-1 of the group at g0
-  for (; g0 + 64 <= pe; g0 += 256) {
-    const bool next_full = g0 + 256 + 64 <= pe;
-    if (!primed) {
-      load_idx(g0, rx, rg);
-#pragma unroll
-      for (int j = 0; j < D; ++j) PCMI_WGRAD_LOAD(j, rx, rg)
-    }
-    if (next_full) load_idx(g0 + 256, rxn, rgn);
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % D][ct], bv[s % D][nt], acc[ct][nt], 0, 0, 0);
-      if (s + D < 32) {
-        PCMI_WGRAD_LOAD(s + D, rx, rg)
-      } else if (next_full) {
-        PCMI_WGRAD_LOAD(s + D - 32, rxn, rgn)
+#if PCMI_ABLATE == 9
+  unsigned long long w_t1 = 0, w_groups = 0;
+#endif
+  if constexpr (BUF) {
+    // Both operands through raw buffer loads with 32-bit byte offsets: the offset of a pair's row is computed once per
+    // 64-pair group (one multiply per lane), a pair past the end of the chunk gets an out-of-range offset and reads
+    // zeros -- the ragged last group of a wave runs through the same D-deep request ring as the full ones.  (The
+    // separate ragged loop below requested, waited and multiplied step by step: at the coarse levels, where an offset
+    // has fewer pairs than one group per wave, that loop WAS the kernel -- 25-33 us for 0.6 GFLOP.)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7FFFFFFF, 0x00020000);
+    const uint32_t xlane = (uint32_t)(c0 + CT * i) * 4, glane = (uint32_t)(n0 + NT * i) * 4;
+    const uint32_t xld = (uint32_t)(a.x_ld * 4), gld = (uint32_t)(a.g_ld * 4);
+    constexpr int D = (CT * NT >= 6) ? 4 : 8;
+    float av[D][CT], bv[D][NT];
+    auto load_off = [&](int64_t g0, uint32_t& ox, uint32_t& og) {
+      const int64_t p = g0 + lane;
+      ox = og = kAbsentRow;
+      if (p < pe) {
+        ox = (uint32_t)(IDX ? a.idx_x[p] : (int32_t)p) * xld;
+        og = (uint32_t)(IDX ? a.idx_g[p] : (int32_t)p) * gld;
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the requests D steps ahead of their use
-    }
-    rx = rxn;
-    rg = rgn;
-    primed = next_full;
+    };
+#define PCMI_WGRAD_BLOAD(J, OX, OG)                                                             \
+  {                                                                                             \
+    const uint32_t x0 = __builtin_amdgcn_readlane(OX, 2 * (J)), x1 = __builtin_amdgcn_readlane(OX, 2 * (J) + 1); \
+    const uint32_t y0 = __builtin_amdgcn_readlane(OG, 2 * (J)), y1 = __builtin_amdgcn_readlane(OG, 2 * (J) + 1); \
+    BufLoad<CT>::ld(xr, (h ? x1 : x0) + xlane, av[(J) % D]);                                    \
+    BufLoad<NT>::ld(gr, (h ? y1 : y0) + glane, bv[(J) % D]);                                    \
   }
-#undef PCMI_WGRAD_LOAD
-  // ragged last group of this wave
-  if (g0 < pe) {
-    const int64_t p = g0 + lane;
-    int32_t tx = -1, tg = -1;
-    if (p < pe) {
-      tx = IDX ? a.idx_x[p] : (int32_t)p;
-      tg = IDX ? a.idx_g[p] : (int32_t)p;
-    }
-    const int npairs = (int)(pe - g0);
-    for (int s = 0; 2 * s < npairs; ++s) {
-      const int32_t ix = __shfl(tx, 2 * s + h, 64);
-      const int32_t ig = __shfl(tg, 2 * s + h, 64);
-      float ta[CT], tb[NT];
-      if (ix >= 0) {
-        VecLoad<CT>::ld(xcol + (int64_t)ix * a.x_ld, ta);
-        VecLoad<NT>::ld(gcol + (int64_t)ig * a.g_ld, tb);
-      } else {
+    int64_t g0 = pb + (int64_t)wave * 64;
+    uint32_t ox = 0, og = 0, oxn = 0, ogn = 0;
+    bool primed = false;
+#if PCMI_ABLATE == 9
+    w_t1 = __builtin_readcyclecounter();
+#endif
+    for (; g0 < pe; g0 += 256) {
+#if PCMI_ABLATE == 9
+      ++w_groups;
+#endif
+      const bool next = g0 + 256 < pe;
+      if (!primed) {
+        load_off(g0, ox, og);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) ta[ct] = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) tb[nt] = 0.f;
+        for (int j = 0; j < D; ++j) PCMI_WGRAD_BLOAD(j, ox, og)
       }
+      if (next) load_off(g0 + 256, oxn, ogn);
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+      for (int s = 0; s < 32; ++s) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[ct], tb[nt], acc[ct][nt], 0, 0, 0);
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % D][ct], bv[s % D][nt], acc[ct][nt], 0, 0, 0);
+        if (s + D < 32) {
+          PCMI_WGRAD_BLOAD(s + D, ox, og)
+        } else if (next) {
+          PCMI_WGRAD_BLOAD(s + D - 32, oxn, ogn)
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the requests D steps ahead of their use
+      }
+      ox = oxn;
+      og = ogn;
+      primed = next;
     }
-  }
+#undef PCMI_WGRAD_BLOAD
+  } else {
+    const float* xcol = a.x + c0 + CT * i;
+    const float* gcol = a.g + n0 + NT * i;
+    // Each wave walks 64-pair groups (group index = wave, wave+4, ...); one group is 32 MFMA contraction steps of two
+    // pairs.  The operand rows of step s+D are requested while step s multiplies (register ring of D steps, running on
+    // into the next group): written as load -> use per step, hipcc emitted global_load -> s_waitcnt vmcnt(0) -> MFMAs,
+    // the whole memory latency in front of every CT*NT MFMAs (SQ_VALU_MFMA_BUSY_CYCLES: 38 %).
+    constexpr int D = (CT * NT >= 6) ? 4 : 8;  // steps in flight: >= ~2000 cycles of matrix work (32 % D == 0)
+    float av[D][CT], bv[D][NT];
+    auto load_idx = [&](int64_t g0, int32_t& rx, int32_t& rg) {
+      const int64_t p = g0 + lane;
+      rx = IDX ? a.idx_x[p] : (int32_t)p;  // IDX is a template flag: a run-time select put an s_waitcnt vmcnt(0) here
+      rg = IDX ? a.idx_g[p] : (int32_t)p;
+    };
+    // operands of contraction step j of a FULL group: lane (i, h) takes pair 2j+h
+  #define PCMI_WGRAD_LOAD(J, RX, RG)                                                            \
+    {                                                                                           \
+      const int32_t ix0 = __builtin_amdgcn_readlane(RX, 2 * (J)), ix1 = __builtin_amdgcn_readlane(RX, 2 * (J) + 1); \
+      const int32_t ig0 = __builtin_amdgcn_readlane(RG, 2 * (J)), ig1 = __builtin_amdgcn_readlane(RG, 2 * (J) + 1); \
+      VecLoad<CT>::ld(xcol + (int64_t)(h ? ix1 : ix0) * a.x_ld, av[(J) % D]);                   \
+      VecLoad<NT>::ld(gcol + (int64_t)(h ? ig1 : ig0) * a.g_ld, bv[(J) % D]);                   \
+    }
+    int64_t g0 = pb + (int64_t)wave * 64;
+    int32_t rx = 0, rg = 0, rxn = 0, rgn = 0;
+    bool primed = false;  // ring holds steps 0..D-1 of the group at g0
+#if PCMI_ABLATE == 9
+    w_t1 = __builtin_readcyclecounter();
+#endif
+    for (; g0 + 64 <= pe; g0 += 256) {
+  #if PCMI_ABLATE == 9
+      ++w_groups;
+  #endif
+      const bool next_full = g0 + 256 + 64 <= pe;
+      if (!primed) {
+        load_idx(g0, rx, rg);
+  #pragma unroll
+        for (int j = 0; j < D; ++j) PCMI_WGRAD_LOAD(j, rx, rg)
+      }
+      if (next_full) load_idx(g0 + 256, rxn, rgn);
+  #pragma unroll
+      for (int s = 0; s < 32; ++s) {
+  #pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s % D][ct], bv[s % D][nt], acc[ct][nt], 0, 0, 0);
+        if (s + D < 32) {
+          PCMI_WGRAD_LOAD(s + D, rx, rg)
+        } else if (next_full) {
+          PCMI_WGRAD_LOAD(s + D - 32, rxn, rgn)
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the requests D steps ahead of their use
+      }
+      rx = rxn;
+      rg = rgn;
+      primed = next_full;
+    }
+  #undef PCMI_WGRAD_LOAD
+    // ragged last group of this wave
+    if (g0 < pe) {
+      const int64_t p = g0 + lane;
+      int32_t tx = -1, tg = -1;
+      if (p < pe) {
+        tx = IDX ? a.idx_x[p] : (int32_t)p;
+        tg = IDX ? a.idx_g[p] : (int32_t)p;
+      }
+      const int npairs = (int)(pe - g0);
+      for (int s = 0; 2 * s < npairs; ++s) {
+        const int32_t ix = __shfl(tx, 2 * s + h, 64);
+        const int32_t ig = __shfl(tg, 2 * s + h, 64);
+        float ta[CT], tb[NT];
+        if (ix >= 0) {
+          VecLoad<CT>::ld(xcol + (int64_t)ix * a.x_ld, ta);
+          VecLoad<NT>::ld(gcol + (int64_t)ig * a.g_ld, tb);
+        } else {
+  #pragma unroll
+          for (int ct = 0; ct < CT; ++ct) ta[ct] = 0.f;
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt) tb[nt] = 0.f;
+        }
+  #pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+  #pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[ct][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[ct], tb[nt], acc[ct][nt], 0, 0, 0);
+      }
+    }
 
+  }
+  WPROF(w_t2);
   // reduce the 4 waves one after the other through ONE LDS tile, wave 0 writes the slab
   for (int src = 1; src < 4; ++src) {
     if (wave == src) {
@@ -270,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   }
   __syncthreads();
   const bool direct = a.mode == kDirect;
-  float* base = direct ? a.gw + (int64_t)k_off * per_k : a.slabs + (int64_t)blockIdx.x * per_k;
+  float* base = direct ? a.gw + (int64_t)k_off * per_k : a.slabs + s_desc[5] * per_k;
   float v[EPT];
   int64_t el[EPT];
 #pragma unroll
@@ -288,6 +447,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < EPT; ++j) base[el[j]] = v[j];
+#if PCMI_ABLATE == 9
+  if (lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024) {
+    unsigned long long* o = g_wgrad_prof + ((size_t)blockIdx.x * 4 + wave) * 8;
+    const unsigned long long w_t3 = __builtin_readcyclecounter();
+    o[0] = w_t3 - w_t0;
+    o[1] = w_t1 - w_t0;
+    o[2] = w_t2 - w_t1;
+    o[3] = w_t3 - w_t2;
+    o[4] = w_groups;
+    o[5] = __builtin_amdgcn_s_getreg(63492);
+    o[6] = __builtin_amdgcn_s_getreg(63508);
+    o[7] = (unsigned long long)(pe - pb);
+  }
+#endif
   if (a.mode != kArrive) return;
   // ---- the last workgroup of this (offset, tile) to arrive sums the slabs in chunk order -------------------------
   const int64_t first = s_desc[3], count = s_desc[4];
@@ -421,20 +594,28 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   if (lane == 0) out[col] = accumulate ? out[col] + s : s;
 }
 
+// buf: both operands are < 2 GiB (32-bit byte offsets); else the 64-bit-address form
 template <int CT, int NT>
-static void launch_wg(const WgradArgs& a, dim3 grid, hipStream_t st) {
-  if (a.idx_x)
-    wgrad_mfma_kernel<CT, NT, true><<<grid, 256, 0, st>>>(a);
-  else
-    wgrad_mfma_kernel<CT, NT, false><<<grid, 256, 0, st>>>(a);
+static void launch_wg(const WgradArgs& a, dim3 grid, bool buf, hipStream_t st) {
+  if (buf) {
+    if (a.idx_x)
+      wgrad_mfma_kernel<CT, NT, true, true><<<grid, 256, 0, st>>>(a);
+    else
+      wgrad_mfma_kernel<CT, NT, false, true><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (a.idx_x)
+      wgrad_mfma_kernel<CT, NT, true, false><<<grid, 256, 0, st>>>(a);
+    else
+      wgrad_mfma_kernel<CT, NT, false, false><<<grid, 256, 0, st>>>(a);
+  }
 }
 
 template <int CT>
-static int launch_wg_nt(int NT, const WgradArgs& a, dim3 grid, hipStream_t st) {
+static int launch_wg_nt(int NT, const WgradArgs& a, dim3 grid, bool buf, hipStream_t st) {
   switch (NT) {
-    case 1: launch_wg<CT, 1>(a, grid, st); break;
-    case 2: launch_wg<CT, 2>(a, grid, st); break;
-    case 3: launch_wg<CT, 3>(a, grid, st); break;
+    case 1: launch_wg<CT, 1>(a, grid, buf, st); break;
+    case 2: launch_wg<CT, 2>(a, grid, buf, st); break;
+    case 3: launch_wg<CT, 3>(a, grid, buf, st); break;
     default: set_error("wgrad: bad NT %d", NT); return PCMI_ERR_INVALID;
   }
   PCMI_LAUNCH_CHECK();
@@ -448,8 +629,8 @@ static int occupancy_wg(bool idx) {
   int& v = cache[idx ? 1 : 0];
   if (v == 0) {
     int n = 0;
-    hipError_t e = idx ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_mfma_kernel<CT, NT, true>, 256, 0)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_mfma_kernel<CT, NT, false>, 256, 0);
+    hipError_t e = idx ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_mfma_kernel<CT, NT, true, true>, 256, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_mfma_kernel<CT, NT, false, true>, 256, 0);
     v = (e == hipSuccess && n > 0) ? std::min(n, 8) : 2;
     (void)hipGetLastError();
   }
@@ -476,10 +657,12 @@ static int tiles_per_wg(int tiles32) {  // tiles (of 32 channels) a workgroup co
   return 1;
 }
 
-// Pairs per workgroup.  Every chunk costs the same, so the launch runs in ceil(workgroups / resident slots)
-// rounds of equal length: 741 workgroups on 512 slots (what M/768 gave for the level-1 96->96 conv) idle half the
-// chip in the second round -- SQ_WAVE_CYCLES showed the waves alive for 47 % of the kernel.  Pick the largest
-// chunk whose workgroup count fills >= 92 % of a whole number of rounds (else the best fill).
+// Pairs per workgroup.  Every chunk costs the same, so the launch runs in ceil(workgroups / resident slots) rounds of
+// equal length, and a round lasts as long as the wave with the most 64-pair groups: ceil(chunk / 256) groups.  Pick
+// the chunk with the smallest rounds x groups (ties: the larger chunk, fewer slabs).  Per-wave cycle accounting
+// (scripts/wgrad_prof.py) of the rule this replaces -- "the largest chunk that fills >= 92 % of a whole number of
+// rounds" -- on the level-1 96->96 gradient: 3200 pairs = 12.5 groups per wave, i.e. half the waves of every workgroup
+// waited one whole group (8 % of the loop) at the reduction barrier, and 480 workgroups on 512 slots.
 constexpr int kWgradMinChunk = 256, kWgradMaxChunk = 4096, kWgradMaxChunks = 1536;
 
 static int wgrad_min_chunk(int64_t M) {
@@ -490,18 +673,17 @@ static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk);
 
 static int wgrad_chunk(const pcmi_kmap_t* map, int64_t M, int64_t wgs_per_chunk, int64_t slots) {
   const int lo = wgrad_min_chunk(M);
-  int best = lo;
-  double best_fill = -1.0;
+  int64_t best_cost = -1;
   for (int c = std::max(lo, kWgradMaxChunk); c >= lo; c -= 128) {
-    const int64_t wgs = wgrad_num_chunks(map, M, c) * wgs_per_chunk;
-    const double fill = (double)wgs / (double)(ceil_div(wgs, slots) * slots);
-    if (fill >= 0.92) return c;
-    if (fill > best_fill) {
-      best_fill = fill;
-      best = c;
-    }
+    const int64_t cost = ceil_div(wgrad_num_chunks(map, M, c) * wgs_per_chunk, slots) * ceil_div(c, 256);
+    if (best_cost < 0 || cost < best_cost) best_cost = cost;
   }
-  return best;
+  // the largest chunk within 4 % of the best: fewer slabs to write and to sum
+  for (int c = std::max(lo, kWgradMaxChunk); c >= lo; c -= 128) {
+    const int64_t cost = ceil_div(wgrad_num_chunks(map, M, c) * wgs_per_chunk, slots) * ceil_div(c, 256);
+    if (cost * 100 <= best_cost * 104) return c;
+  }
+  return lo;
 }
 
 static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk) {
@@ -613,16 +795,22 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   PCMI_REQUIRE(ws && ws_bytes >= slab_bytes + bias_bytes, PCMI_ERR_WORKSPACE,
                "spconv_bwd_weight: workspace %zu < %zu bytes", ws_bytes, slab_bytes + bias_bytes);
   a.slabs = (float*)ws;
+  const int64_t grid_x = nchunks;
   if (stem) {
     stem_wgrad_kernel<3><<<dim3((unsigned)nchunks), 256, 0, st>>>(a);
     PCMI_LAUNCH_CHECK();
   } else {
-    dim3 grid((unsigned)nchunks, (unsigned)(cin / (32 * CT)), (unsigned)(cout / (32 * NT)));
+    dim3 grid((unsigned)grid_x, (unsigned)(cin / (32 * CT)), (unsigned)(cout / (32 * NT)));
+    const bool buf_ok = [] {  // PCMI_WGRAD_BUF=0: always the 64-bit-address form (A/B, parity of the two; read per call)
+      const char* e = getenv("PCMI_WGRAD_BUF");
+      return !(e && e[0] == '0');
+    }();
+    const bool buf = buf_ok && n_in * in_ld * 4 <= 0x7FFFFF00ll && n_out * gout_ld * 4 <= 0x7FFFFF00ll;
     int rc;
     switch (CT) {
-      case 1: rc = launch_wg_nt<1>(NT, a, grid, st); break;
-      case 2: rc = launch_wg_nt<2>(NT, a, grid, st); break;
-      default: rc = launch_wg_nt<3>(NT, a, grid, st); break;
+      case 1: rc = launch_wg_nt<1>(NT, a, grid, buf, st); break;
+      case 2: rc = launch_wg_nt<2>(NT, a, grid, buf, st); break;
+      default: rc = launch_wg_nt<3>(NT, a, grid, buf, st); break;
     }
     if (rc) return rc;
   }
@@ -650,6 +838,12 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
 }  // namespace pcmi
 
 extern "C" {
+
+#if PCMI_ABLATE == 9
+int pcmi_debug_wgrad_prof(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wgrad_prof), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? PCMI_OK : PCMI_ERR_HIP;
+}
+#endif
 
 int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
                            int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,

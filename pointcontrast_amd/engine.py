@@ -180,6 +180,7 @@ class NativeEngine:
     self._h = create_net(prog, n_passes)
     self._held = [None] * n_passes
     self._pair_stream = None
+    self.pair_marks = None
 
   def __del__(self):
     try:
@@ -226,13 +227,35 @@ class NativeEngine:
       self._pair_stream = torch.cuda.Stream(device=dev)
     side = self._pair_stream
     side.wait_stream(cur)  # inputs / parameters were produced on the current stream
+    marks = self.pair_marks  # None, or a list: timing events of the two forwards (bench: misc.gpu_profile)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if marks is not None else None
     with torch.cuda.stream(side):
+      if ev:
+        ev[0].record(side)
       f1 = self.forward(1, st1, defer_running_stats=True)
+      if ev:
+        ev[1].record(side)
+    if ev:
+      ev[2].record(cur)
     f0 = self.forward(0, st0)
+    if ev:
+      ev[3].record(cur)
+      marks.append(ev)
     cur.wait_stream(side)
     f1.record_stream(cur)
     self.apply_running_stats(1)
     return f0, f1
+
+  def pair_marks_ms(self, skip=0):
+    """Mean stream times of the recorded forward pairs (after a synchronize): pass 1 on its stream, pass 0 on the
+    current one, and how far pass 0's first kernel trails pass 1's."""
+    m = (self.pair_marks or [])[skip:]
+    if not m:
+      return {}
+    avg = lambda f: round(sum(f(e) for e in m) / len(m), 3)
+    return {"pass1": avg(lambda e: e[0].elapsed_time(e[1])), "pass0": avg(lambda e: e[2].elapsed_time(e[3])),
+            "pass0_starts_after_pass1_start": avg(lambda e: e[0].elapsed_time(e[2])),
+            "pass0_ends_after_pass1_end": avg(lambda e: e[1].elapsed_time(e[3]))}
 
   def backward(self, pass_id, d_out, reducer=None):
     """Accumulates parameter gradients of pass `pass_id` into flat.g.  With a GradReducer the

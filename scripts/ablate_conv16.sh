@@ -9,11 +9,13 @@ B=pointcontrast_amd/csrc/_build
 for n in ${ABLATIONS:-1 2 3 4 5}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mcode-object-version=5 -Wno-unused-function -DPCMI_ABLATE=$n \
     -c pointcontrast_amd/csrc/spconv.hip -o $B/spconv_abl$n.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mcode-object-version=5 -Wno-unused-function -DPCMI_ABLATE=$n \
+    -c pointcontrast_amd/csrc/spconv_wgrad.hip -o $B/spconv_wgrad_abl$n.o &
 done
 wait
 for n in ${ABLATIONS:-1 2 3 4 5}; do
-  objs=$(ls $B/*.o | grep -v "spconv\.o" | grep -v "_abl")
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o pointcontrast_amd/libpcmi_abl$n.so $objs $B/spconv_abl$n.o
+  objs=$(ls $B/*.o | grep -v "spconv\.o" | grep -v "spconv_wgrad\.o" | grep -v "_abl")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o pointcontrast_amd/libpcmi_abl$n.so $objs $B/spconv_abl$n.o $B/spconv_wgrad_abl$n.o
 done
 cp pointcontrast_amd/libpcmi.so pointcontrast_amd/libpcmi_abl0.so
 ls -la pointcontrast_amd/libpcmi_abl*.so

@@ -959,3 +959,27 @@ def test_conv16_pipelined_matches_unpipelined(ME, size, cin, cout, monkeypatch):
     else:  # the unit-balanced launch of the pipelined form cuts its shares at chunk steps, not at offsets: same sums, other grouping
       assert_close(res["1"][0], res["0"][0], 1e-5, "forward, unit-balanced")
       assert_close(res["1"][1], res["0"][1], 1e-5, "backward-data, unit-balanced")
+
+
+@pytest.mark.parametrize("size,cin,cout", [("small", 64, 96), ("mid", 128, 32), ("large", 96, 96), ("tiny", 256, 256)])
+def test_wgrad_buffer_form_is_bit_identical(ME, size, cin, cout, monkeypatch):
+  """wgrad_mfma_kernel<.., BUF = true> (32-bit byte offsets, raw buffer loads, the ragged last group of a wave padded
+  with out-of-range pairs that read zeros) against the 64-bit-address form with its separate ragged loop
+  (PCMI_WGRAD_BUF=0): same pairs in the same order -> identical bits."""
+  from pointcontrast_amd import functional as PF
+  C = _coords(size)
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  torch.manual_seed(4)
+  g = torch.randn(len(C), cout, device=DEV)
+  res = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("PCMI_WGRAD_BUF", mode)
+    W = (torch.randn(27, cin, cout, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6)) / (cin * 27) ** 0.5).requires_grad_(True)
+    x = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    y = PF.SparseConvFunction.apply(x, W, None, m, False, len(C), cm)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res[mode] = W.grad.clone()
+  assert torch.equal(res["1"], res["0"])
