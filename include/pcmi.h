@@ -74,6 +74,13 @@ int pcmi_coords_destroy(pcmi_coords_t* h);
 int pcmi_coords_reset(pcmi_coords_t* h);
 /* Build the hash of n rows -> key 0.  Syncs (returns PCMI_ERR_DUPLICATE / PCMI_ERR_RANGE). */
 int pcmi_coords_insert(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream);
+/* Two-segment batches (the two point clouds of a contrastive pair processed as ONE sparse tensor: the reference runs
+ * its network once per cloud, ddp_trainer.py:404-407, so BatchNorm statistics are per cloud).  The caller inserts the
+ * rows of the first cloud before those of the second, with disjoint batch indices, and declares the boundary;
+ * pcmi_coords_split returns the boundary of any level (strided levels keep first-occurrence order, so the segments
+ * stay contiguous) or -1 when none was declared.  set_split: after insert, before the first stride. */
+int pcmi_coords_set_split(pcmi_coords_t* h, int64_t n_first);
+int pcmi_coords_split(pcmi_coords_t* h, int key, int64_t* n_first);
 /* Strided coordinates: unique floor(c / (stride*ts)) * (stride*ts); rows are in
  * first-occurrence order of the input rows.  Cached per tensor stride.  Syncs on a miss. */
 int pcmi_coords_stride(pcmi_coords_t* h, int in_key, int stride, int* out_key, int64_t* n_out,

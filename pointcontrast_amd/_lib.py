@@ -69,6 +69,8 @@ PROTOTYPES = {
     "pcmi_coords_stride": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(c_i64), c_vp]),
     "pcmi_coords_key_at_stride": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_int)]),
     "pcmi_coords_size": (C.c_int, [c_vp, C.c_int, C.POINTER(c_i64), C.POINTER(C.c_int)]),
+    "pcmi_coords_set_split": (C.c_int, [c_vp, c_i64]),
+    "pcmi_coords_split": (C.c_int, [c_vp, C.c_int, C.POINTER(c_i64)]),
     "pcmi_coords_get": (C.c_int, [c_vp, C.c_int, c_vp, c_vp]),
     "pcmi_coords_plan_unet": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int, c_vp]),
     "pcmi_coords_arena_bytes": (C.c_int, [c_vp, C.POINTER(c_sz)]),

@@ -85,6 +85,7 @@ struct Level {
   uint32_t cap = 0;
   int32_t* parent = nullptr;  // valid once the next coarser level exists
   int child_key = -1;         // key of that coarser level
+  int64_t split = -1;         // >= 0: rows [0, split) belong to the first segment (pcmi_coords_set_split)
 };
 
 struct MapEntry {
@@ -532,6 +533,21 @@ int pcmi_coords_size(pcmi_coords_t* h, int key, int64_t* n, int* tensor_stride) 
   return PCMI_OK;
 }
 
+int pcmi_coords_set_split(pcmi_coords_t* h, int64_t n_first) {
+  PCMI_REQUIRE(h && !h->levels.empty(), PCMI_ERR_INVALID, "coords_set_split: insert the coordinates first");
+  PCMI_REQUIRE(h->levels.size() == 1, PCMI_ERR_INVALID, "coords_set_split: strided levels exist already");
+  PCMI_REQUIRE(n_first >= 0 && n_first <= h->levels[0].n, PCMI_ERR_INVALID, "coords_set_split: %lld of %lld rows",
+               (long long)n_first, (long long)h->levels[0].n);
+  h->levels[0].split = n_first;
+  return PCMI_OK;
+}
+
+int pcmi_coords_split(pcmi_coords_t* h, int key, int64_t* n_first) {
+  PCMI_REQUIRE(h && n_first && key >= 0 && key < (int)h->levels.size(), PCMI_ERR_NOKEY, "coords_split: unknown key %d", key);
+  *n_first = h->levels[key].split;
+  return PCMI_OK;
+}
+
 int pcmi_coords_key_at_stride(pcmi_coords_t* h, int tensor_stride, int* key) {
   PCMI_REQUIRE(h && key, PCMI_ERR_INVALID, "null argument");
   for (size_t i = 0; i < h->levels.size(); ++i)
@@ -583,9 +599,17 @@ int pcmi_coords_stride(pcmi_coords_t* h, int in_key, int stride, int* out_key, i
   PCMI_LAUNCH_CHECK();
   rc = exclusive_scan<true>(flags, n, pos, h->d_total, h->scratch, st);
   if (rc) return rc;
+  // segment boundary of the coarse level: its rows are in first-occurrence order of the fine rows and a cell never
+  // has children in both segments (they differ in the batch index), so it is the number of first occurrences among
+  // the fine rows [0, split) = pos[split]
+  const int64_t fsplit = h->levels[in_key].split;
+  const bool carry = fsplit > 0 && fsplit < n;
+  h->h_pinned[1] = 0;
+  if (carry) PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + 1, pos + fsplit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   rc = read_back(h, h->d_total, 8, st);
   if (rc) return rc;
   C.n = h->h_pinned[0];
+  C.split = fsplit < 0 ? -1 : (carry ? (int64_t)(h->h_pinned[1] & 0xFFFFFFFFll) : (fsplit >= n ? C.n : 0));
   C.coords = h->persistent.alloc_n<int32_t>(C.n * 4);
   if (!C.coords) return PCMI_ERR_HIP;
   stride_parent_kernel<<<grid, 256, 0, st>>>(fine, n, ts2, C.hvals, slot_of, pos, parent, C.coords);

@@ -109,6 +109,7 @@ struct PassState {
   std::vector<pcmi_kmap_t> maps;   // per op
   std::vector<char> has_map;
   std::vector<int64_t> rows;       // per level
+  std::vector<int64_t> split;      // per level: rows of the first segment (= rows when the pass has one segment)
   const float* in_feats = nullptr;
   int64_t in_ld = 0;
   float* out_feats = nullptr;
@@ -314,7 +315,7 @@ struct BackwardRun {
     }
     int rc = ps->grad.reserve(off, st);
     if (rc) return rc;
-    rc = ps->small.reserve((size_t)2 * max_c * sizeof(float) + 256, st);
+    rc = ps->small.reserve((size_t)4 * max_c * sizeof(float) + 256, st);  // per segment: dbeta, dgamma
     if (rc) return rc;
     scratch_g = (float*)ps->small.p;
     deferred = job.role == BackwardJob::DEFERRED;
@@ -396,8 +397,13 @@ struct BackwardRun {
         PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sidx], 0));
         side_pending = true;
       }
-      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
-                                  gdst + op.w_off, op.has_bias ? gdst + op.b_off : nullptr, gacc, wws->p, wws->cap, wst);
+      static const bool skip_wgrad = [] {  // timing experiments only (gradients are WRONG): the chain without its shadow
+        const char* e = getenv("PCMI_DEBUG_SKIP_WGRAD");
+        return e && e[0] == '1';
+      }();
+      if (!skip_wgrad)
+        rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
+                                    gdst + op.w_off, op.has_bias ? gdst + op.b_off : nullptr, gacc, wws->p, wws->cap, wst);
       if (rc) return rc;
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
@@ -408,19 +414,40 @@ struct BackwardRun {
       const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
       View dr = {nullptr, 0};
       if (op.in2 >= 0) dr = grad_view(n, *ps, op.in2, d_out, d_ld);
-      const float* stats = (const float*)(ps->act.p + ps->stat_off[i]);
+      const float* stats0 = (const float*)(ps->act.p + ps->stat_off[i]);
       float* dgamma = scratch_g;
       float* dbeta = scratch_g + op.cout;
       float* acc_g = grads + op.w_off;
       float* acc_b = grads + op.b_off;
+      const int64_t sp = ps->split[n.tensors[op.in].level];
+      const int n_seg = sp < n_in ? 2 : 1;
       if (deferred) {  // the sums ARE this pass's parameter gradients: stored straight into the peer buffer
+        PCMI_REQUIRE(n_seg == 1, PCMI_ERR_UNSUPPORTED, "net_backward_pair: two-segment passes run solo");
         dgamma = gdst + op.w_off;
         dbeta = gdst + op.b_off;
         acc_g = acc_b = nullptr;
       }
-      rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats,
-                       stats + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps->ws.p,
-                       ps->ws.cap, st);
+      static const bool seg_fused = [] {
+        const char* e = getenv("PCMI_BN_SEG_FUSED");
+        return !(e && e[0] == '0');
+      }();
+      if (n_seg == 2 && !seg_fused) {
+        for (int seg = 0; seg < 2 && !rc; ++seg) {
+          const int64_t r0 = seg ? sp : 0, cnt = seg ? n_in - sp : sp;
+          const float* stats = stats0 + seg * 3 * op.cout;
+          rc = bn_backward(dy.p + r0 * dy.ld, dy.ld, x.p + r0 * x.ld, x.ld, op.relu ? y.p + r0 * y.ld : nullptr, y.ld, cnt,
+                           op.cout, params + op.w_off, stats, stats + op.cout, dx.p + r0 * dx.ld, dx.ld,
+                           dr.p ? dr.p + r0 * dr.ld : nullptr, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps->ws.p,
+                           ps->ws.cap, st);
+        }
+      } else if (n_seg == 2)  // a segment = one forward call of the reference: own statistics, own sums; one launch pair
+        rc = bn_backward2(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, sp, op.cout, params + op.w_off, stats0,
+                          stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, acc_g, acc_b,
+                          ps->ws.p, ps->ws.cap, st);
+      else
+        rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats0,
+                         stats0 + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps->ws.p,
+                         ps->ws.cap, st);
     } else {
       const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
       rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps->act.p + ps->stat_off[i]), n_in, op.cout, dx.p, dx.ld,
@@ -586,6 +613,15 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     rc = pcmi_coords_stride(coords, keys[l - 1], 2, &keys[l], &ps.rows[l], stream);
     if (rc) return rc;
   }
+  // two-segment batch (pcmi_coords_set_split): BatchNorm normalises every segment with its own statistics, as two
+  // forward calls of the reference would
+  ps.split.assign(n.n_levels, 0);
+  for (int l = 0; l < n.n_levels; ++l) {
+    int64_t sp = -1;
+    rc = pcmi_coords_split(coords, keys[l], &sp);
+    if (rc) return rc;
+    ps.split[l] = (sp <= 0 || sp >= ps.rows[l]) ? ps.rows[l] : sp;
+  }
   g_prof_fwd.lap(0);
   // ---- maps, arena layout, workspace --------------------------------------------------------------
   ps.maps.resize(n_ops);
@@ -624,7 +660,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
     ps.stat_off[i] = off;
-    if (op.type == PCMI_OP_BN) off += align_up((size_t)3 * op.cout * sizeof(float), 256);  // mean, invstd, unbiased var
+    if (op.type == PCMI_OP_BN) off += align_up((size_t)2 * 3 * op.cout * sizeof(float), 256);  // per segment: mean, invstd, unbiased var
     if (op.type == PCMI_OP_L2NORM) off += align_up((size_t)ps.rows[n.tensors[op.in].level] * sizeof(float), 256);
   }
   rc = ps.act.reserve(off, st);
@@ -632,8 +668,11 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   rc = ps.ws.reserve(ws_need + 256, st);
   if (rc) return rc;
   const bool train = (training & 1) != 0, defer = train && (training & PCMI_NET_DEFER_RUNNING_STATS) != 0;
+  bool two_seg = false;  // a two-segment pass updates the running estimates through the table as well (segment 0, then 1)
+  for (int l = 0; l < n.n_levels; ++l) two_seg |= ps.split[l] < ps.rows[l];
+  two_seg &= train;
   ps.upd_n = 0;
-  if (defer) {
+  if (defer || two_seg) {
     int n_bn = 0;
     for (int i = 0; i < n_ops; ++i) n_bn += n.ops[i].type == PCMI_OP_BN;
     if (n_bn > ps.upd_cap) {
@@ -666,13 +705,40 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     } else if (op.type == PCMI_OP_BN) {
       View r = {nullptr, 0};
       if (op.in2 >= 0) r = act_view(n, ps, op.in2);
-      float* stats = (float*)(ps.act.p + ps.stat_off[i]);
+      float* stats0 = (float*)(ps.act.p + ps.stat_off[i]);
       if (train) {
-        rc = bn_forward_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off,
-                              defer ? nullptr : op.running_mean, defer ? nullptr : op.running_var, op.momentum, op.eps, r.p,
-                              r.ld, op.relu, y.p, y.ld, stats, stats + op.cout, stats + 2 * op.cout, ps.ws.p, ps.ws.cap, st);
-        if (defer && op.running_mean)
-          ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats, stats + 2 * op.cout, op.cout, op.momentum};
+        const int64_t sp = ps.split[n.tensors[op.in].level];
+        float* stats1 = stats0 + 3 * op.cout;
+        static const bool seg_fused = [] {  // PCMI_BN_SEG_FUSED=0: one BatchNorm call per segment (A/B, debugging)
+          const char* e = getenv("PCMI_BN_SEG_FUSED");
+          return !(e && e[0] == '0');
+        }();
+        if (sp < n_in && !seg_fused) {
+          for (int seg = 0; seg < 2 && !rc; ++seg) {
+            const int64_t r0 = seg ? sp : 0, cnt = seg ? n_in - sp : sp;
+            float* stats = stats0 + seg * 3 * op.cout;
+            rc = bn_forward_train(x.p + r0 * x.ld, x.ld, cnt, op.cout, params + op.w_off, params + op.b_off, nullptr, nullptr,
+                                  op.momentum, op.eps, r.p ? r.p + r0 * r.ld : nullptr, r.ld, op.relu, y.p + r0 * y.ld, y.ld,
+                                  stats, stats + op.cout, stats + 2 * op.cout, ps.ws.p, ps.ws.cap, st);
+          }
+          if (op.running_mean)
+            ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
+                                       stats1, stats1 + 2 * op.cout};
+        } else if (sp < n_in) {  // both segments in one statistics launch + one apply launch; running estimates via the table
+          rc = bn_forward_train2(x.p, x.ld, n_in, sp, op.cout, params + op.w_off, params + op.b_off, op.eps, r.p, r.ld, op.relu,
+                                 y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, 3 * op.cout, ps.ws.p, ps.ws.cap, st);
+          if (op.running_mean)
+            ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
+                                       stats1, stats1 + 2 * op.cout};
+        } else {
+          const bool tab = defer || two_seg;
+          rc = bn_forward_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off,
+                                tab ? nullptr : op.running_mean, tab ? nullptr : op.running_var, op.momentum, op.eps, r.p,
+                                r.ld, op.relu, y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, ps.ws.p, ps.ws.cap, st);
+          if (tab && op.running_mean)
+            ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
+                                       nullptr, nullptr};
+        }
       } else {
         rc = pcmi_bn_fwd_eval(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
                               op.running_var, op.eps, r.p, r.ld, op.relu, y.p, y.ld, stream);
@@ -683,9 +749,14 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     if (rc) return rc;
     g_prof_fwd.lap(op.type == PCMI_OP_CONV ? 3 : (op.type == PCMI_OP_BN ? 4 : 5));
   }
-  if (defer && ps.upd_n > 0) {
+  if ((defer || two_seg) && ps.upd_n > 0) {
     PCMI_HIP_CHECK(hipMemcpyAsync(ps.upd_dev, ps.upd_host, sizeof(BnRunningUpdate) * ps.upd_n, hipMemcpyHostToDevice, st));
     PCMI_HIP_CHECK(hipEventRecord(ps.upd_copied, st));
+    if (!defer) {  // two-segment pass without a deferral request: apply now, in layer order
+      rc = bn_running_update(ps.upd_dev, ps.upd_n, st);
+      if (rc) return rc;
+      ps.upd_n = 0;
+    }
   }
   g_prof_fwd.lap(6);
   static const char* const kFwdNames[] = {"levels", "maps", "layout+reserve", "conv", "bn", "l2norm", "tail"};

@@ -43,7 +43,16 @@ struct BnRunningUpdate {
   const float* unbiased;
   int c;
   float momentum;
+  const float* mean2;      // nullable: statistics of the second segment of a two-segment pass, applied after the first
+  const float* unbiased2;
 };
+int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, int c, const float* gamma, const float* beta,
+                      float eps, const float* residual, int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean,
+                      float* save_invstd, float* save_unbiased, int stat_stride, void* ws, size_t ws_bytes, hipStream_t st);
+int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld, int64_t n,
+                 int64_t split, int c, const float* gamma, const float* save_mean, const float* save_invstd, int stat_stride,
+                 float* dx, int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* sums, float* acc_dgamma,
+                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
 int bn_running_update(const BnRunningUpdate* table_dev, int n_entries, hipStream_t st);
 
 size_t sort_rows_temp_bytes(int64_t n);

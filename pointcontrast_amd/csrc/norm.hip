@@ -94,6 +94,8 @@ struct RedFinal {
   float* out_b;
   float* acc_a;
   float* acc_b;
+  // two-segment launches (gridDim.y == 2, see colreduce_partial_kernel): floats between the segments' outputs
+  int out_seg_stride;
 };
 
 // MODE 0: (sum x, sum x^2) per block -> (mean_b, M2_b)
@@ -103,13 +105,46 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld,
     const float* __restrict__ ymask, int64_t y_ld, const float* __restrict__ mean,
     const float* __restrict__ invstd, int64_t n, int c4, int rp, int rows_per_block,
-    float* __restrict__ part /* [nblocks][2][c] */, RedFinal fin) {
+    float* __restrict__ part /* [nblocks][2][c] */, RedFinal fin, int64_t seg_split = 0, int in_seg_stride = 0,
+    int64_t part_seg_stride = 0) {
   __shared__ float4 s_a[256];
   __shared__ float4 s_b[256];
   __shared__ unsigned s_last;
   const int t = threadIdx.x;
   const int col = t % c4, rl = t / c4;
   const int c = c4 * 4;
+  // gridDim.y == 2: the rows [0, seg_split) and [seg_split, n) are two independent reductions (the two point clouds
+  // of a pair in one sparse tensor: BatchNorm statistics per cloud) in ONE launch, each with its own partials,
+  // arrival counter and outputs
+  int64_t base = 0;
+  if (gridDim.y > 1) {
+    const int sg = blockIdx.y;
+    base = sg ? seg_split : 0;
+    n = sg ? n - seg_split : seg_split;
+    part += sg * part_seg_stride;
+    if (MODE == 1) {
+      mean += sg * in_seg_stride;
+      invstd += sg * in_seg_stride;
+    }
+    if (fin.counter) {
+      fin.counter += sg;
+      const int os = sg * fin.out_seg_stride;
+      if (MODE == 0) {
+        fin.save_mean += os;
+        fin.save_invstd += os;
+        if (fin.save_unbiased) fin.save_unbiased += os;
+      } else {
+        fin.out_a += os;
+        fin.out_b += os;
+      }
+    }
+    if ((int64_t)blockIdx.x * rows_per_block >= n) return;  // the shorter segment has fewer row blocks
+  }
+  x += base * x_ld;
+  if (MODE == 1) {
+    dy += base * dy_ld;
+    if (ymask) ymask += base * y_ld;
+  }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(r0 + (int64_t)rows_per_block, n);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -183,8 +218,8 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
   // channels (coalesced float4 loads, independent of each other), then the c4 column threads fold the rp lanes
   // through LDS.  (A thread-per-channel loop over all blocks was one L2 latency per block: 20 us for 80 blocks.)
   if (fin.counter == nullptr) return;
-  if (!arrive_last(fin.counter, gridDim.x, &s_last)) return;
-  const int nblocks = (int)gridDim.x;
+  const int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);  // (= gridDim.x for a one-segment launch)
+  if (!arrive_last(fin.counter, (unsigned)nblocks, &s_last)) return;
   __shared__ float s_n[256];
   float cnt = 0.f;
   a = make_float4(0.f, 0.f, 0.f, 0.f);  // MODE 0: running mean, MODE 1: sum a
@@ -329,14 +364,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd_or_var, float eps,
                                                        int use_var, const float* __restrict__ res,
                                                        int64_t res_ld, int relu, float* __restrict__ y,
-                                                       int64_t y_ld) {
+                                                       int64_t y_ld, int64_t seg_split = INT64_MAX, int seg_stride4 = 0) {
   const int64_t total = n * c4;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t r = idx / c4;
     const int col = (int)(idx - r * c4);
+    const int sc = col + (r >= seg_split ? seg_stride4 : 0);  // rows of the second segment: its own statistics
     const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-    const float4 mu = reinterpret_cast<const float4*>(mean)[col];
-    float4 is = reinterpret_cast<const float4*>(invstd_or_var)[col];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[sc];
+    float4 is = reinterpret_cast<const float4*>(invstd_or_var)[sc];
     if (use_var) {
       is.x = 1.0f / sqrtf(is.x + eps); is.y = 1.0f / sqrtf(is.y + eps);
       is.z = 1.0f / sqrtf(is.z + eps); is.w = 1.0f / sqrtf(is.w + eps);
@@ -365,12 +401,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ ymask, int64_t y_ld, int64_t n, int c4, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ sum_g,
     const float* __restrict__ sum_gx, float* __restrict__ dx, int64_t dx_ld, float* __restrict__ dres,
-    int64_t dres_ld, int dres_accumulate) {
+    int64_t dres_ld, int dres_accumulate, int64_t seg_split = INT64_MAX, int stat_stride4 = 0, int sum_stride4 = 0,
+    float* __restrict__ acc_g = nullptr, float* __restrict__ acc_gx = nullptr) {
   const int64_t total = n * c4;
-  const float inv_n = 1.0f / (float)n;
+  const bool two = seg_split < n;
+  const float inv_n0 = 1.0f / (float)(two ? seg_split : n), inv_n1 = two ? 1.0f / (float)(n - seg_split) : 0.f;
+  if (acc_g && blockIdx.x == 0 && threadIdx.x < c4) {
+    // two-segment launch: the parameter gradients (acc + sums of segment 0) + sums of segment 1, in that order --
+    // what two consecutive one-segment calls accumulate
+    float4 a = reinterpret_cast<float4*>(acc_g)[threadIdx.x], b = reinterpret_cast<float4*>(acc_gx)[threadIdx.x];
+    for (int sg = 0; sg < (two ? 2 : 1); ++sg) {
+      const float4 u = reinterpret_cast<const float4*>(sum_g)[threadIdx.x + sg * sum_stride4];
+      const float4 v = reinterpret_cast<const float4*>(sum_gx)[threadIdx.x + sg * sum_stride4];
+      a = make_float4(a.x + u.x, a.y + u.y, a.z + u.z, a.w + u.w);
+      b = make_float4(b.x + v.x, b.y + v.y, b.z + v.z, b.w + v.w);
+    }
+    reinterpret_cast<float4*>(acc_g)[threadIdx.x] = a;
+    reinterpret_cast<float4*>(acc_gx)[threadIdx.x] = b;
+  }
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t r = idx / c4;
     const int col = (int)(idx - r * c4);
+    const bool second = r >= seg_split;
+    const float inv_n = second ? inv_n1 : inv_n0;
+    const int sc = col + (second ? stat_stride4 : 0), uc = col + (second ? sum_stride4 : 0);
     float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
     if (ymask) {
       const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
@@ -378,11 +432,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
     const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
-    const float4 mu = reinterpret_cast<const float4*>(mean)[col];
-    const float4 is = reinterpret_cast<const float4*>(invstd)[col];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[sc];
+    const float4 is = reinterpret_cast<const float4*>(invstd)[sc];
     const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
-    const float4 sg = reinterpret_cast<const float4*>(sum_g)[col];
-    const float4 sx = reinterpret_cast<const float4*>(sum_gx)[col];
+    const float4 sg = reinterpret_cast<const float4*>(sum_g)[uc];
+    const float4 sx = reinterpret_cast<const float4*>(sum_gx)[uc];
     float4 o;
     o.x = ga.x * is.x * (g.x - sg.x * inv_n - (xv.x - mu.x) * is.x * sx.x * inv_n);
     o.y = ga.y * is.y * (g.y - sg.y * inv_n - (xv.y - mu.y) * is.y * sx.y * inv_n);
@@ -542,11 +596,100 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
   return PCMI_OK;
 }
 
+// Two-segment BatchNorm forward (rows [0, split) and [split, n): own statistics each) in two launches: statistics of
+// both segments (gridDim.y = 2, fused final), then one apply pass.  save_*: [2][3c] blocks (mean, invstd, unbiased)
+// `stat_stride` floats apart; the running estimates are the caller's business (BnRunningUpdate with mean2).
+int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, int c, const float* gamma, const float* beta,
+                      float eps, const float* residual, int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean,
+                      float* save_invstd, float* save_unbiased, int stat_stride, void* ws, size_t ws_bytes, hipStream_t st) {
+  int rc = check_rows("bn_fwd_train2(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_fwd_train2(y)", y, y_ld, c);
+  if (rc) return rc;
+  if (residual && (rc = check_rows("bn_fwd_train2(residual)", residual, res_ld, c))) return rc;
+  PCMI_REQUIRE(gamma && beta && save_mean && save_invstd && split > 0 && split < n && stat_stride % 4 == 0, PCMI_ERR_INVALID,
+               "bn_fwd_train2: bad argument");
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_fwd_train2: workspace too small");
+  const int64_t longest = std::max(split, n - split);
+  RedGeom g = red_geom(longest, c);
+  if (g.nblocks > kFuseFinalBlocks) {  // at most kFuseFinalBlocks row blocks per segment: the final merge stays fused
+    g.rows_per_block = (int)(ceil_div(ceil_div(longest, kFuseFinalBlocks), g.rp) * g.rp);
+    g.nblocks = (int)ceil_div(longest, g.rows_per_block);
+  }
+  float* part = (float*)ws;
+  RedFinal fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.counter = stream_counters(st, 2);
+  if (!fin.counter) return PCMI_ERR_HIP;
+  fin.eps = eps;
+  fin.save_mean = save_mean;
+  fin.save_invstd = save_invstd;
+  fin.save_unbiased = save_unbiased;
+  fin.out_seg_stride = stat_stride;
+  colreduce_partial_kernel<0><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, n,
+                                                                           g.c4, g.rp, g.rows_per_block, part, fin, split, 0,
+                                                                           (int64_t)g.nblocks * 2 * c);
+  PCMI_LAUNCH_CHECK();
+  bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
+                                                        res_ld, relu, y, y_ld, split, stat_stride / 4);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+// Two-segment BatchNorm backward.  sums: [2][2c] scratch (dbeta, dgamma per segment); acc_*: parameter gradients
+// (+= segment 0, then += segment 1).
+int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld, int64_t n,
+                 int64_t split, int c, const float* gamma, const float* save_mean, const float* save_invstd, int stat_stride,
+                 float* dx, int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* sums, float* acc_dgamma,
+                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st) {
+  int rc = check_rows("bn_bwd2(dy)", dy, dy_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_bwd2(x)", x, x_ld, c);
+  if (rc) return rc;
+  rc = check_rows("bn_bwd2(dx)", dx, dx_ld, c);
+  if (rc) return rc;
+  if (relu_mask_y && (rc = check_rows("bn_bwd2(y)", relu_mask_y, y_ld, c))) return rc;
+  if (dres && (rc = check_rows("bn_bwd2(dres)", dres, dres_ld, c))) return rc;
+  PCMI_REQUIRE(gamma && save_mean && save_invstd && sums && split > 0 && split < n && stat_stride % 4 == 0, PCMI_ERR_INVALID,
+               "bn_bwd2: bad argument");
+  PCMI_REQUIRE(ws && ws_bytes >= pcmi_bn_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "bn_bwd2: workspace too small");
+  const int64_t longest = std::max(split, n - split);
+  RedGeom g = red_geom(longest, c);
+  if (g.nblocks > kFuseFinalBlocks) {
+    g.rows_per_block = (int)(ceil_div(ceil_div(longest, kFuseFinalBlocks), g.rp) * g.rp);
+    g.nblocks = (int)ceil_div(longest, g.rows_per_block);
+  }
+  float* part = (float*)ws;
+  RedFinal fin;
+  memset(&fin, 0, sizeof(fin));
+  fin.counter = stream_counters(st, 2);
+  if (!fin.counter) return PCMI_ERR_HIP;
+  fin.out_a = sums;      // dbeta of a segment
+  fin.out_b = sums + c;  // dgamma
+  fin.out_seg_stride = 2 * c;
+  colreduce_partial_kernel<1><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
+                                                                           save_invstd, n, g.c4, g.rp, g.rows_per_block, part,
+                                                                           fin, split, stat_stride, (int64_t)g.nblocks * 2 * c);
+  PCMI_LAUNCH_CHECK();
+  bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
+                                                            save_invstd, sums, sums + c, dx, dx_ld, dres, dres_ld,
+                                                            dres_accumulate, split, stat_stride / 4, 2 * c / 4, acc_dbeta,
+                                                            acc_dgamma);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
 __global__ __launch_bounds__(256) void bn_running_update_kernel(const BnRunningUpdate* __restrict__ tab) {
   const BnRunningUpdate u = tab[blockIdx.x];
   for (int ch = threadIdx.x; ch < u.c; ch += 256) {
-    u.running_mean[ch] = (1.f - u.momentum) * u.running_mean[ch] + u.momentum * u.mean[ch];
-    u.running_var[ch] = (1.f - u.momentum) * u.running_var[ch] + u.momentum * u.unbiased[ch];
+    float rm = (1.f - u.momentum) * u.running_mean[ch] + u.momentum * u.mean[ch];
+    float rv = (1.f - u.momentum) * u.running_var[ch] + u.momentum * u.unbiased[ch];
+    if (u.mean2) {  // second segment of the same layer: the second of two forward calls
+      rm = (1.f - u.momentum) * rm + u.momentum * u.mean2[ch];
+      rv = (1.f - u.momentum) * rv + u.momentum * u.unbiased2[ch];
+    }
+    u.running_mean[ch] = rm;
+    u.running_var[ch] = rv;
   }
 }
 

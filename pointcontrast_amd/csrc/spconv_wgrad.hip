@@ -663,7 +663,18 @@ static int tiles_per_wg(int tiles32) {  // tiles (of 32 channels) a workgroup co
 // (scripts/wgrad_prof.py) of the rule this replaces -- "the largest chunk that fills >= 92 % of a whole number of
 // rounds" -- on the level-1 96->96 gradient: 3200 pairs = 12.5 groups per wave, i.e. half the waves of every workgroup
 // waited one whole group (8 % of the loop) at the reduction barrier, and 480 workgroups on 512 slots.
-constexpr int kWgradMinChunk = 256, kWgradMaxChunk = 4096, kWgradMaxChunks = 1536;
+constexpr int kWgradMinChunk = 256, kWgradMaxChunks = 4096;
+// PCMI_WGRAD_MAX_CHUNK: longest chunk (pairs).  A workgroup of the level-1 gradients runs ~80 us per 1024 pairs and is
+// never pre-empted: while it holds its CU, the latency-critical kernels of the bwd-data chain (higher stream priority,
+// but priority only orders the DISPATCH of new workgroups) wait for a slot.
+static int wgrad_max_chunk() {
+  static const int v = [] {
+    const char* e = getenv("PCMI_WGRAD_MAX_CHUNK");
+    const int c = e ? atoi(e) : 4096;
+    return std::max(256, c / 128 * 128);
+  }();
+  return v;
+}
 
 static int wgrad_min_chunk(int64_t M) {
   return (int)std::max<int64_t>(kWgradMinChunk, align_up((size_t)ceil_div(M, kWgradMaxChunks), 128));
@@ -674,12 +685,12 @@ static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk);
 static int wgrad_chunk(const pcmi_kmap_t* map, int64_t M, int64_t wgs_per_chunk, int64_t slots) {
   const int lo = wgrad_min_chunk(M);
   int64_t best_cost = -1;
-  for (int c = std::max(lo, kWgradMaxChunk); c >= lo; c -= 128) {
+  for (int c = std::max(lo, wgrad_max_chunk()); c >= lo; c -= 128) {
     const int64_t cost = ceil_div(wgrad_num_chunks(map, M, c) * wgs_per_chunk, slots) * ceil_div(c, 256);
     if (best_cost < 0 || cost < best_cost) best_cost = cost;
   }
   // the largest chunk within 4 % of the best: fewer slabs to write and to sum
-  for (int c = std::max(lo, kWgradMaxChunk); c >= lo; c -= 128) {
+  for (int c = std::max(lo, wgrad_max_chunk()); c >= lo; c -= 128) {
     const int64_t cost = ceil_div(wgrad_num_chunks(map, M, c) * wgs_per_chunk, slots) * ceil_div(c, 256);
     if (cost * 100 <= best_cost * 104) return c;
   }

@@ -206,8 +206,9 @@ class NativeEngine:
       check(lib.pcmi_net_forward(self._h, pass_id, cm._h, ptr(x), x.stride(0), n, ptr(self.flat.w), mode, ptr(out),
                                  self.out_channels, cur_stream(x.device)))
     if training:
+      calls = 2 if getattr(cm, "n_first", None) not in (None, 0, n) else 1  # a two-segment batch is two forward calls
       for m in self._bn_modules:
-        m._untracked += 1
+        m._untracked += calls
       self._held[pass_id] = (st, x, out)  # coordinates / input / output stay alive until backward
     return out
 

@@ -144,6 +144,19 @@ class CoordsManager:
     check(lib.pcmi_coords_size(self._h, key.key if isinstance(key, CoordsKey) else int(key), C.byref(n), C.byref(ts)))
     return n.value
 
+  def set_split(self, n_first):
+    """Declares a two-segment batch: rows [0, n_first) are the first point cloud of a pair, the rest the second
+    (disjoint batch indices).  The native engine then keeps BatchNorm statistics per segment, as the reference's two
+    forward calls do (pcmi_coords_set_split).  Call before any strided level exists."""
+    check(lib.pcmi_coords_set_split(self._h, int(n_first)))
+    self.n_first = int(n_first)
+
+  def split(self, key=0):
+    """Rows of the first segment at `key` (None: single-segment batch)."""
+    v = C.c_int64()
+    check(lib.pcmi_coords_split(self._h, key.key if isinstance(key, CoordsKey) else int(key), C.byref(v)))
+    return None if v.value < 0 else v.value
+
   def key(self, k):
     n, ts = C.c_int64(), C.c_int()
     check(lib.pcmi_coords_size(self._h, int(k), C.byref(n), C.byref(ts)))

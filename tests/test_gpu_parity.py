@@ -983,3 +983,95 @@ def test_wgrad_buffer_form_is_bit_identical(ME, size, cin, cout, monkeypatch):
     torch.cuda.synchronize()
     res[mode] = W.grad.clone()
   assert torch.equal(res["1"], res["0"])
+
+
+@pytest.mark.parametrize("name,crop,batch,seed", [("Res16UNet14", 0.6, 1, 5), ("Res16UNet14", 0.6, 1, 7), ("Res16UNet34C", 0.9, 2, 6)])
+def test_joint_pair_pass_matches_two_passes(ME, name, crop, batch, seed):
+  """The two clouds of a pair as ONE two-segment sparse tensor (trainer: misc.joint_pair; pcmi_coords_set_split) against
+  one engine pass per cloud -- what the reference does (ddp_trainer.py:404-407): the convolutions never mix batch
+  indices and BatchNorm keeps statistics per segment, so the features agree to fp32 round-off, the running estimates
+  (segment 0, then segment 1) too, and the strided levels keep the segments contiguous.
+  Parameter gradients: the pair against the two single passes at 1e-4 with every BatchNorm shift set to +8, where ReLU is
+  the identity.  (With shifts near 0 a pre-activation within round-off of zero lands on the other side of the kink
+  when the statistics are merged over a different row-block partition -- even for a cloud paired with a copy of
+  itself -- and whole gradient tensors move by percents, of that cloud only and whichever segment it is run as:
+  scripts/joint_grad_noise.py, and the note at test_network_features_loss_and_grads.  The iteration-level tests
+  against the oracle run the joint pass with the ordinary shifts.)"""
+  from pointcontrast_amd.engine import NativeEngine
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.distributed import FlatParameters
+  cfg = get_config([])
+  _, dev = _make_models(name, cfg, seed=3)
+  dev.train()
+  flat = FlatParameters(dev.parameters())
+  eng = NativeEngine(dev, flat)
+  b = synthetic.make_batch(seed=seed, batch_size=batch, crop=crop)
+  F = [torch.from_numpy(b["sinput%s_F" % s]) for s in "01"]
+  Cs = [torch.from_numpy(b["sinput%s_C" % s]) for s in "01"]
+  names = {id(p): n for n, p in dev.named_parameters()}
+
+  def shifted(C, by):
+    C = C.clone()
+    C[:, 0] += int(by[:, 0].max()) + 1
+    return C
+
+  def joint_tensor(Fa, Ca, Fb, Cb):
+    sj = ME.SparseTensor(torch.cat([Fa, Fb]), coords=torch.cat([Ca, shifted(Cb, Ca)])).to(DEV)
+    sj.coords_man.set_split(Ca.shape[0])
+    return sj
+
+  def worst(a, e):
+    scale = float(a.abs().max())
+    per = []
+    for i, p in enumerate(flat.params):
+      x, y = flat.view(a, i), flat.view(e, i)
+      per.append((float((x - y).abs().max()) / max(float(x.abs().max()), 1e-4 * scale), names[id(p)]))
+    per.sort(reverse=True)
+    return per[0][0], "; ".join("%s %.2e" % (n, v) for v, n in per[:5])
+
+  sts = [ME.SparseTensor(F[i], coords=Cs[i]).to(DEV) for i in range(2)]
+  rs = {k: v.clone() for k, v in dev.state_dict().items() if "running" in k}
+  fe = [eng.forward(i, sts[i]) for i in range(2)]
+  rs_two = {k: v.clone() for k, v in dev.state_dict().items() if "running" in k}
+  g = [torch.randn_like(f) for f in fe]
+  dev.load_state_dict({**dev.state_dict(), **rs})
+  # ---- the pair as one tensor: features, running estimates, segment boundaries ----
+  n0 = Cs[0].shape[0]
+  sj = joint_tensor(F[0], Cs[0], F[1], Cs[1])
+  fj = eng.forward(0, sj)
+  cm, key, lvl = sj.coords_man, sj.coords_key, 0
+  while True:  # every level: rows of cloud 0 first
+    sp, n = cm.split(key), cm.size(key)
+    assert sp is not None and 0 < sp < n
+    first = cm.get_coords(key)[:, 0].cpu() <= int(Cs[0][:, 0].max())
+    assert bool(first[:sp].all()) and not bool(first[sp:].any()), "level %d: segments are not contiguous" % lvl
+    if lvl == eng.n_down:
+      break
+    key, lvl = cm.stride(key, 2), lvl + 1
+  assert_close(fj[:n0], fe[0], 1e-5, "%s joint features, cloud 0" % name)
+  assert_close(fj[n0:], fe[1], 1e-5, "%s joint features, cloud 1" % name)
+  for k, v in dev.state_dict().items():
+    if "running" in k:
+      assert_close(v, rs_two[k], 1e-5, "joint " + k)
+  # ---- (b): the real pair, with every BatchNorm shift raised to +8: no pre-activation is near zero (8 sigma), ReLU is
+  # the identity in both evaluations and the comparison is one of linear algebra only ----
+  with torch.no_grad():
+    for n_, p_ in dev.named_parameters():
+      if n_.endswith("bn.bias"):
+        p_.fill_(8.0)
+  for i in range(2):
+    eng.forward(i, sts[i])
+  flat.zero_grad()
+  eng.backward(1, g[1])
+  eng.backward(0, g[0])
+  g_two = flat.g.clone()
+  eng.forward(0, sj)
+  flat.zero_grad()
+  eng.backward(0, torch.cat(g))
+  err, msg = worst(g_two, flat.g)
+  assert err <= 1e-4, "joint backward vs the two single passes (kink-free weights), worst gradient tensors: " + msg
+  with torch.no_grad():
+    for n_, p_ in dev.named_parameters():
+      if n_.endswith("bn.bias"):
+        p_.fill_(0.0)
