@@ -55,6 +55,20 @@ def get_batch(seed, batch_size, voxel_size):
   return {k: torch.from_numpy(np.ascontiguousarray(d[k])) for k in keys}
 
 
+def level1_tensor(batch, device, joint=True):
+  """The full-resolution sparse tensor as the training step launches on it: with misc.joint_pair (default) BOTH clouds
+  of the pair as one two-segment tensor, else cloud 0."""
+  import torch
+  import pointcontrast_amd.minkowski as ME
+  if not joint:
+    return ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(device)
+  C0, C1 = batch["sinput0_C"], batch["sinput1_C"].clone()
+  C1[:, 0] += int(C0[:, 0].max()) + 1
+  st = ME.SparseTensor(torch.cat([batch["sinput0_F"], batch["sinput1_F"]]), coords=torch.cat([C0, C1])).to(device)
+  st.coords_man.set_split(C0.shape[0])
+  return st
+
+
 def conv_work(model):
   """Algorithmic FLOPs / bytes of one forward from the real per-layer pair counts
   (flops = 2*M*Cin*Cout; bytes = M*(4*Cin + 8) + N_out*4*Cout + 4*K*Cin*Cout)."""
@@ -96,15 +110,16 @@ def time_kernel(fn, iters=20, warm=3, warm_ms=40.0):
   return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def kernel_rooflines(batch, device):
-  """Times the hot kernels in isolation on the level-1 map of cloud 0 (HIP events)."""
+def kernel_rooflines(batch, device, joint=True):
+  """Times the hot kernels in isolation on the level-1 map the training step uses (HIP events): the pair as one
+  two-segment tensor with misc.joint_pair, else cloud 0."""
   import torch
   import pointcontrast_amd.minkowski as ME
   from pointcontrast_amd import functional as PF
   from pointcontrast_amd._lib import lib, check
   from pointcontrast_amd.runtime import ptr, cur_stream, ws_args
   import ctypes as C
-  st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(device)
+  st = level1_tensor(batch, device, joint)
   cm, key = st.coords_man, st.coords_key
   n = st.F.shape[0]
   m = cm.kernel_map(key, key, 3, 1, 3)
@@ -147,7 +162,7 @@ def kernel_rooflines(batch, device):
     out.append(ent)
     return ent
 
-  dominant = conv_entry("spconv_mfma fwd 3^3 96->96 @level1", 96, 96, m, 27, n, n)
+  dominant = conv_entry("spconv16p fwd 3^3 96->96 @level1 (%d rows)" % n, 96, 96, m, 27, n, n)
   conv_entry("spconv_mfma bwd_data 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_data")
   conv_entry("wgrad_mfma 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
   conv_entry("spconv_mfma fwd 3^3 128->96 @level1", 128, 96, m, 27, n, n)
@@ -344,7 +359,10 @@ def main():
         "config": {"workload": "%s: %s, %s loss, voxel %.3g m, %d pairs/GPU, %d+%d active voxels per "
                                "forward pair on rank 0, npos 4096, T 0.4, SGD(lr 0.1, mom 0.8, wd 1e-4)"
                                % (workload_label(args), args.model, args.loss, args.voxel, args.batch, n0, n1),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine, "final_loss": round(loss_val, 5),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine,
+                   "pair_execution": ("one two-segment pass (BatchNorm statistics per cloud)"
+                                      if args.engine == "native" and cfg.misc.get("joint_pair", True) else "one pass per cloud"),
+                   "final_loss": round(loss_val, 5),
                    "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),
                    **({"forward_pair_ms": trainer.engine.pair_marks_ms(skip=args.warmup)}
@@ -366,7 +384,7 @@ def main():
           f.write("\t".join(str(v) for v in r) + "\n")
     log("timed region done: %.2f ms/step" % (elapsed / args.steps * 1e3))
     if not args.no_roofline:
-      dom, kernels = kernel_rooflines(batch, device)
+      dom, kernels = kernel_rooflines(batch, device, joint=bool(cfg.misc.get("joint_pair", True)) and args.engine == "native")
       log("rooflines done")
       # HBM-side bytes per launch of the same kernel / shape from the separate rocprofv3 --pmc passes
       # (scripts/pmc_probe.py -> scripts/pmc_summary.py -> profiles/pmc_traffic.json); null if never collected

@@ -10,7 +10,7 @@ from pointcontrast_amd.runtime import ptr, cur_stream, ws_args
 
 dev = torch.device("cuda:0")
 batch = bench.get_batch(0, 4, 0.025)
-st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(dev)
+st = bench.level1_tensor(batch, dev, joint=os.environ.get("PROBE_JOINT", "1") == "1")  # as the training step launches it
 cm = st.coords_man
 cm.plan_unet(4)
 key = st.coords_key

@@ -11,13 +11,7 @@ from pointcontrast_amd.runtime import ptr, cur_stream, ws_args
 
 dev = torch.device("cuda:0")
 batch = bench.get_batch(0, 4, 0.025)
-if os.environ.get("KBENCH_JOINT") == "1":  # both clouds of the pair as one two-segment tensor (trainer: misc.joint_pair)
-  C0, C1 = batch["sinput0_C"], batch["sinput1_C"].clone()
-  C1[:, 0] += int(C0[:, 0].max()) + 1
-  st = ME.SparseTensor(torch.cat([batch["sinput0_F"], batch["sinput1_F"]]), coords=torch.cat([C0, C1])).to(dev)
-  st.coords_man.set_split(C0.shape[0])
-else:
-  st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(dev)
+st = bench.level1_tensor(batch, dev, joint=os.environ.get("KBENCH_JOINT", "1") == "1")  # default: as the training step
 cm = st.coords_man
 cm.plan_unet(4)
 keys = [st.coords_key]

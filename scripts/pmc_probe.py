@@ -20,7 +20,7 @@ print("CAL eltwise_kernel<2> read_bytes=%d write_bytes=%d" % (2 * n * c * 4, n *
 del a, b, y
 
 batch = bench.get_batch(0, 4, 0.025)
-st = ME.SparseTensor(batch["sinput0_F"], coords=batch["sinput0_C"]).to(dev)
+st = bench.level1_tensor(batch, dev, joint=os.environ.get("PROBE_JOINT", "1") == "1")  # as the training step launches it
 cm, key = st.coords_man, st.coords_key
 m = cm.kernel_map(key, key, 3, 1, 3)
 N = st.F.shape[0]

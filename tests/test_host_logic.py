@@ -197,6 +197,7 @@ def test_prefetch_thread_keeps_batch_order_and_reraises(built_lib):
   tr.config = get_config([])
   tr.cur_device = torch.device("cpu")
   tr._prefetch_thread, tr._prefetch_err, tr._prefetched = None, None, None
+  tr.engine = None  # per-layer path: the helper thread is the default
   seen_threads = []
 
   def fake_prepare(input_dict, draws=None):
@@ -219,6 +220,15 @@ def test_prefetch_thread_keeps_batch_order_and_reraises(built_lib):
   # fixed draws (parity tests) bypass the helper thread entirely
   tr._prefetch_start(it, {"uniform": None})
   assert tr._prefetch_thread is None
+  # native engine with the pair as one two-segment pass (the default): no prefetch unless asked for explicitly
+  tr.engine = object()
+  assert tr._prefetch_mode() is None
+  tr.config = get_config(["misc.prefetch_thread=True"])
+  assert tr._prefetch_mode() == "thread"
+  tr.config = get_config(["misc.prefetch_thread=False"])
+  assert tr._prefetch_mode() == "inline"
+  tr.config = get_config(["misc.joint_pair=False"])
+  assert tr._prefetch_mode() == "thread"
 
 
 def test_scannet_match_pair_dataset_and_infinite_loader(tmp_path):
