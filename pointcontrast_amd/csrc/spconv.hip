@@ -33,6 +33,7 @@
 
 #include "common.h"
 #include "internal.h"
+#include "spconv_args.h"
 
 namespace pcmi {
 
@@ -41,35 +42,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));  // first-class vector: H
 
 constexpr int kKC = 32;  // contraction channels per staged weight chunk
 
-struct ConvArgs {
-  const float* x;        // gathered operand [*, x_ld]
-  int64_t x_ld;
-  int C;                 // contraction size (multiple of 32)
-  const float* w;        // weights [K][cin][cout] in memory
-  int64_t w_kstride;     // floats per weight slice (cin*cout)
-  int64_t w_sc, w_sn;    // B_k[c][n] = w[wk*w_kstride + c*w_sc + n*w_sn]
-  int N;                 // output channels (multiple of 32)
-  const int32_t* nbr;    // [K][n_rows] or nullptr (identity); the permuted table when perm is set
-  const int32_t* perm;   // nullable: tile position -> output row (mask-sorted processing order)
-  const int32_t* pair_src;  // pair mode: gather row per pair
-  const int32_t* pair_dst;  // pair mode: output row per pair
-  const int64_t* offs;   // pair mode: [K+1] device group offsets
-  int K;                 // number of offsets
-  int32_t wsel[PCMI_MAX_KERNEL_VOLUME];  // weight slice used by offset k
-  int64_t n_rows;        // output rows
-  float* out;            // [n_rows, out_ld]  (or partial buffer when ksplit > 1)
-  int64_t out_ld;
-  int64_t split_stride;  // floats between partial buffers
-  int ksplit;            // offsets are divided into ksplit contiguous ranges over blockIdx.z
-  const float* bias;     // nullable, only when ksplit == 1
-  int xcd_tiles;         // > 0: tiles per XCD of the XCD-contiguous tile order (grid.x = 8 * xcd_tiles)
-  int accumulate;        // out += result instead of out = result (only when ksplit == 1)
-  // unit-balanced mode (SK kernels): see spconv_mfma_kernel
-  const uint32_t* sk_mask;  // [n_tiles] occupied offsets of a tile
-  const int32_t* sk_pref;   // [n_tiles + 1] units before a tile
-  int sk_tiles;
-  float* sk_part;           // [gridDim.x][2][128][N] partial tiles
-};
 
 // Weight chunk [KC x 32*NT] global -> registers -> LDS (NT * KC / 32 float4 per thread).  WT: B[c][n] = W[n][c]
 // (backward-data).
@@ -1315,6 +1287,15 @@ static bool conv16_pipelined() {
   return !e || atoi(e) != 0;
 }
 
+// PCMI_CONV16_X3=1: the split-precision form (spconv_x3.hip: fp32 operands as three bf16 terms on the bf16 matrix
+// cores) for the matrix-bound launches of the 16-row kernel (>= 64 channels on both sides).  Off by default.
+static bool conv16_x3(int NT, int C, int N) {
+  const char* e = getenv("PCMI_CONV16_X3");
+  return e && atoi(e) != 0 && NT >= 2 && NT <= 4 && C >= 64 && N >= 64;
+}
+// resident workgroups per CU of spconv16x_kernel (LDS: 2 weight blocks of 6 KiB x NT + the 13.5 KiB offset table)
+static int x3_workgroups(int NT) { return (NT <= 3 ? 3 : 2) * num_cu() / 8 * 8; }
+
 template <bool WT, bool SK>
 static int launch16(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   if (conv16_pipelined()) {
@@ -1474,6 +1455,7 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
   a.sk_pref = nullptr;
   a.sk_tiles = 0;
   a.sk_part = nullptr;
+  a.wpack = nullptr;
   if (pair_mode) {
     a.pair_src = swap_pairs ? map->pair_in : map->pair_out;
     a.pair_dst = swap_pairs ? map->pair_out : map->pair_in;
@@ -1496,8 +1478,11 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
       map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64) {
-    const int G = conv16_enabled(n_rows, x_rows * x_ld * 4) ? sk_workgroups(p.NT) : sk_workgroups(4);
-    const size_t need = sk_partial_bytes(n_rows, N, a.K);
+    const bool c16 = conv16_enabled(n_rows, x_rows * x_ld * 4);
+    const bool x3 = c16 && conv16_x3(p.NT, C, N);
+    const int G = x3 ? x3_workgroups(p.NT) : (c16 ? sk_workgroups(p.NT) : sk_workgroups(4));
+    const size_t part = sk_partial_bytes(n_rows, N, a.K);
+    const size_t need = part + (x3 ? x3_pack_bytes(a.K, C, N) : 0);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
     a.sk_mask = map->tile_mask;
     a.sk_pref = map->tile_pref;
@@ -1505,16 +1490,29 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     a.sk_part = (float*)ws;
     dim3 grid((unsigned)G, (unsigned)(N / (32 * p.NT)), 1);
     int rc;
-    if (conv16_enabled(n_rows, x_rows * x_ld * 4))
+    if (x3) {
+      a.wpack = (char*)ws + part;
+      rc = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
+      if (rc == PCMI_OK) rc = x3_launch(p.NT, true, a, grid, st);
+    } else if (c16)
       rc = w_transposed ? launch16<true, true>(p.NT, a, grid, st) : launch16<false, true>(p.NT, a, grid, st);
     else
       rc = w_transposed ? launch_sk<true>(p.NT, a, grid, st) : launch_sk<false>(p.NT, a, grid, st);
     if (rc) return rc;
-    const int sub = (conv16_enabled(n_rows, x_rows * x_ld * 4) && conv16_pipelined()) ? C / kKC : 1;
+    const int sub = (x3 || (c16 && conv16_pipelined())) ? C / kKC : 1;
     sk_fixup_kernel<<<dim3((unsigned)a.sk_tiles), 256, 0, st>>>(a.sk_part, a.sk_pref, a.sk_tiles, G, a.perm, n_rows, N, bias,
                                                               out, out_ld, accumulate, sub);
     PCMI_LAUNCH_CHECK();
     return PCMI_OK;
+  }
+  const bool x3 = p.RW == 4 && map && conv16_enabled(n_rows, x_rows * x_ld * 4) && conv16_x3(p.NT, C, N);
+  const size_t split_bytes = p.ksplit > 1 ? align_up((size_t)p.ksplit * n_rows * N * sizeof(float), 256) : 0;
+  if (x3) {
+    PCMI_REQUIRE(ws && ws_bytes >= split_bytes + x3_pack_bytes(a.K, C, N), PCMI_ERR_WORKSPACE,
+                 "spconv: workspace %zu < %zu bytes", ws_bytes, split_bytes + x3_pack_bytes(a.K, C, N));
+    a.wpack = (char*)ws + split_bytes;
+    const int rc_pack = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
+    if (rc_pack) return rc_pack;
   }
   if (p.ksplit > 1) {
     const size_t need = (size_t)p.ksplit * n_rows * N * sizeof(float);
@@ -1533,7 +1531,9 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
   }
   dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), (unsigned)p.ksplit);
   int rc;
-  if (p.RW == 4 && conv16_enabled(n_rows, x_rows * x_ld * 4)) {
+  if (x3) {
+    rc = x3_launch(p.NT, false, a, grid, st);
+  } else if (p.RW == 4 && conv16_enabled(n_rows, x_rows * x_ld * 4)) {
     rc = w_transposed ? launch16<true, false>(p.NT, a, grid, st) : launch16<false, false>(p.NT, a, grid, st);
   } else if (p.RW == 4 && (w_transposed ? launch_deep<true>(p.NT, a, grid, st) : launch_deep<false>(p.NT, a, grid, st))) {
     rc = PCMI_OK;
@@ -1553,7 +1553,10 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
 size_t spconv_fwd_bwd_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K) {
   const size_t ks = std::max(partial_bytes(n_out, cout, K), partial_bytes(n_in, cin, K));
   const size_t sk = n_in == n_out ? std::max(sk_partial_bytes(n_out, cout, K), sk_partial_bytes(n_in, cin, K)) : 0;
-  return std::max(ks, sk);
+  // the packed weights of the split-precision form sit behind the partial tiles (whether or not it is switched on:
+  // <= 10.6 MB for the widest layer)
+  const size_t pack = (K > 1 && cin % 32 == 0 && cout % 32 == 0) ? x3_pack_bytes(K, cin, cout) : 0;
+  return align_up(std::max(ks, sk), 256) + pack;
 }
 
 }  // namespace pcmi

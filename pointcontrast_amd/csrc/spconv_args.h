@@ -1,0 +1,47 @@
+// Launch arguments shared by the gathered-GEMM kernels of spconv.hip and spconv_x3.hip.
+#pragma once
+#include "common.h"
+
+namespace pcmi {
+
+struct ConvArgs {
+  const float* x;        // gathered operand [*, x_ld]
+  int64_t x_ld;
+  int C;                 // contraction size (multiple of 32)
+  const float* w;        // weights [K][cin][cout] in memory
+  int64_t w_kstride;     // floats per weight slice (cin*cout)
+  int64_t w_sc, w_sn;    // B_k[c][n] = w[wk*w_kstride + c*w_sc + n*w_sn]
+  int N;                 // output channels (multiple of 32)
+  const int32_t* nbr;    // [K][n_rows] or nullptr (identity); the permuted table when perm is set
+  const int32_t* perm;   // nullable: tile position -> output row (mask-sorted processing order)
+  const int32_t* pair_src;  // pair mode: gather row per pair
+  const int32_t* pair_dst;  // pair mode: output row per pair
+  const int64_t* offs;   // pair mode: [K+1] device group offsets
+  int K;                 // number of offsets
+  int32_t wsel[PCMI_MAX_KERNEL_VOLUME];  // weight slice used by offset k
+  int64_t n_rows;        // output rows
+  float* out;            // [n_rows, out_ld]  (or partial buffer when ksplit > 1)
+  int64_t out_ld;
+  int64_t split_stride;  // floats between partial buffers
+  int ksplit;            // offsets are divided into ksplit contiguous ranges over blockIdx.z
+  const float* bias;     // nullable, only when ksplit == 1
+  int xcd_tiles;         // > 0: tiles per XCD of the XCD-contiguous tile order (grid.x = 8 * xcd_tiles)
+  int accumulate;        // out += result instead of out = result (only when ksplit == 1)
+  // unit-balanced mode (SK kernels): see spconv_mfma_kernel
+  const uint32_t* sk_mask;  // [n_tiles] occupied offsets of a tile
+  const int32_t* sk_pref;   // [n_tiles + 1] units before a tile
+  int sk_tiles;
+  float* sk_part;           // [gridDim.x][2][128][N] partial tiles
+  // split-precision form (spconv_x3.hip): the weights as three bf16 terms in the kernel's LDS image order
+  const void* wpack;
+};
+
+// ---- spconv_x3.hip: fp32 convolution on the bf16 matrix cores (three-term operand split) ---------------------------
+// bytes of the packed weights of one launch (all K slices, every chunk / output slice), 256-byte aligned
+size_t x3_pack_bytes(int K, int C, int N);
+// packs B_k[c][n] = w[k * w_kstride + c * w_sc + n * w_sn] for k < K into `out` (x3_pack_bytes) for NT-wide slices
+int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st);
+// the 128-row-tile kernel itself (a.wpack set; grid as for spconv16p_kernel); NT in {2, 3, 4}
+int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st);
+
+}  // namespace pcmi

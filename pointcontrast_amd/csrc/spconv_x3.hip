@@ -1,0 +1,479 @@
+// fp32 sparse convolution on the BF16 matrix cores of gfx950: three-term operand split ("bf16x3").
+//
+// Why.  gfx950 has no reduced-precision fast path for fp32 inputs (no xf32): v_mfma_f32_16x16x4_f32 runs at the fp32
+// VECTOR rate, 1/16 of the bf16 rate (MI355X_MICROARCH.md: 157 TFLOP/s against 2.5 PFLOP/s).  The reference's
+// arithmetic is fp32 and north_star holds the features to 1e-4, so plain bf16 is not an option -- but an fp32 number
+// is the EXACT sum of three bf16 numbers,
+//     x = h + m + l,   h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)        (round-to-nearest-even, 3 x 8 bits)
+// and a product of two such sums, truncated after the terms of relative size 2^-16,
+//     a b  ~  a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_m b_m + a_l b_h)       (dropped: <= 2^-23 |a b|)
+// is six bf16 MFMAs with fp32 accumulation: 6/16 of the matrix-pipe time of the fp32 instruction for the same tile,
+// at fp32-class accuracy (every bf16 x bf16 product is exact in fp32; one rounding per MFMA instead of one per
+// product).  tests/test_gpu_parity.py::test_conv16_x3_* measures both forms against an fp64 contraction.
+//
+// What.  spconv16x_kernel is spconv16p_kernel (spconv.hip: 128-row tiles, two 16-row groups per wave, per-group offset
+// skipping, byte-offset neighbour table, raw buffer loads issued from inside the MFMA stream, unit-balanced launch)
+// with the inner product replaced:
+//   * weights: x3_pack_kernel splits them ONCE per launch into the kernel's LDS image -- per (slice k, 32-channel chunk,
+//     NS-wide output slice) a block [term h|m|l][column n][lane quad kk][8 bf16] -- so staging a chunk is a linear
+//     16-byte copy and a B fragment (8 bf16 = the 8 channels lane (j, kk) contracts) is ONE conflict-free ds_read_b128
+//     (a wave reads 1 KiB contiguous);
+//   * gathered rows: fp32 in memory as before (same HBM / L2 traffic); the 8 floats a lane holds per group and chunk are
+//     split in registers (v_cvt_pk_bf16_f32, 5.5 VALU operations per element, issued beside the other waves' MFMAs);
+//   * v_mfma_f32_16x16x32_bf16: lane (i = l & 15, kk = l >> 4) supplies A[i][8 kk .. 8 kk + 7] and B[8 kk ..][j = i];
+//     which eight channels those are is free as long as A and B agree: channel(kk, e) = 4 kk + (e & 3) + 16 (e >> 2)
+//     (the two float4 the lane gathers).  C/D layout as the fp32 16x16 form: D[row = 4 kk + r][col = i].
+// Opt-in (PCMI_CONV16_X3=1) until it has been through the whole GPU suite.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "internal.h"
+#include "spconv_args.h"
+
+namespace pcmi {
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kKC = 32;  // contraction channels per staged chunk = per MFMA
+
+// two floats -> two bf16 (round to nearest even) packed in one dword, first value in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// 8 floats (element e = x0[e] for e < 4, x1[e - 4] otherwise) -> three vectors of 8 bf16 with x = h + m + l
+__device__ __forceinline__ void split3(const v4f& x0, const v4f& x1, u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float xa = p < 2 ? x0[2 * p] : x1[2 * p - 4], xb = p < 2 ? x0[2 * p + 1] : x1[2 * p - 3];
+    const unsigned hp = cvt_pk_bf16(xa, xb);
+    const float ra = xa - bf16_lo(hp), rb = xb - bf16_hi(hp);  // exact
+    const unsigned mp = cvt_pk_bf16(ra, rb);
+    const float sa = ra - bf16_lo(mp), sb = rb - bf16_hi(mp);  // exact
+    h[p] = hp;
+    m[p] = mp;
+    l[p] = cvt_pk_bf16(sa, sb);
+  }
+}
+
+// channel of chunk-local element e of lane quad kk (see the header)
+__host__ __device__ constexpr int x3_channel(int kk, int e) { return 4 * kk + (e & 3) + 16 * (e >> 2); }
+
+// One thread per (slice, chunk, output slice, column, lane quad): the three 16-byte pieces of that lane's B fragment.
+__global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ w, int64_t w_kstride, int64_t w_sc, int64_t w_sn,
+                                                      int K, int C, int N, int NS, u32x4* __restrict__ out) {
+  const int nch = C / kKC, nns = N / NS;
+  const int64_t total = (int64_t)K * nch * nns * NS * 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int kk = (int)(idx & 3);
+  int64_t r = idx >> 2;
+  const int nl = (int)(r % NS);
+  r /= NS;
+  const int ns = (int)(r % nns);
+  r /= nns;
+  const int cc = (int)(r % nch);
+  const int wk = (int)(r / nch);
+  const float* wb = w + (int64_t)wk * w_kstride + (int64_t)(ns * NS + nl) * w_sn;
+  v4f x0, x1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x0[e] = wb[(int64_t)(cc * kKC + x3_channel(kk, e)) * w_sc];
+    x1[e] = wb[(int64_t)(cc * kKC + x3_channel(kk, e + 4)) * w_sc];
+  }
+  u32x4 h, m, l;
+  split3(x0, x1, h, m, l);
+  u32x4* blk = out + (((int64_t)wk * nch + cc) * nns + ns) * (3 * NS * 4);
+  blk[(0 * NS + nl) * 4 + kk] = h;
+  blk[(1 * NS + nl) * 4 + kk] = m;
+  blk[(2 * NS + nl) * 4 + kk] = l;
+}
+
+// DMA: the weight block of the next step goes global -> LDS directly (buffer_load_dwordx4 ... lds: the block is a
+// linear image, a wave instruction copies 1 KiB) instead of through 4 x BR staging registers per thread -- at NT = 3
+// that is what lets the kernel fit 3 waves per SIMD without spilling (185 -> 165 VGPRs).
+template <int NT, bool SK, bool DMA>
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArgs a) {
+  constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
+  constexpr int KSLOTS = PCMI_MAX_KERNEL_VOLUME;
+  constexpr uint32_t kAbsent = 0x80000000u;
+  constexpr int kRsrcFlags = 0x00020000;  // raw buffer, 32-bit data format
+  constexpr int PIECES = 3 * NS * 4;      // 16-byte pieces of one weight block
+  constexpr int BLOCK_BYTES = PIECES * 16;
+  constexpr int BR = (PIECES + 255) / 256;  // staging rounds of a thread
+  static_assert(CTN >= 3, "the three load stages sit behind the MFMAs of column tiles 0, 1, 2");
+  __shared__ __attribute__((aligned(16))) u32x4 s_b[2][PIECES];
+  __shared__ uint32_t s_off[KSLOTS][TM];
+  __shared__ int32_t s_orow[TM];
+  __shared__ int2 s_kmeta[KSLOTS];  // per occupied offset: {row of s_off, byte offset of its first weight block}
+  __shared__ int32_t s_kabs[KSLOTS];
+  __shared__ int32_t s_nk;
+  __shared__ int64_t s_tile[2];
+
+  const int n0 = blockIdx.y * NS;
+  const int nch = a.C / kKC;
+  const uint32_t chunk_bytes = (uint32_t)gridDim.y * BLOCK_BYTES;  // blocks of one chunk: one per output slice
+  const uint32_t wk_bytes = (uint32_t)nch * chunk_bytes;
+  const uint32_t slice_bytes = (uint32_t)blockIdx.y * BLOCK_BYTES;
+  int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
+  bool sk_first = true;
+  if constexpr (SK) {
+    const int G = (int)gridDim.x;
+    sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
+    const int U = a.sk_pref[a.sk_tiles] * nch;  // shares are counted in chunk steps (see spconv16p_kernel)
+    const int per = (U + G - 1) / G;
+    sk_u = sk_g * per;
+    sk_u1 = min(U, sk_u + per);
+    if (sk_u >= sk_u1) return;
+    if (threadIdx.x < 64) {  // last tile whose first step is <= sk_u: 64-ary search
+      int lo = 0, n = a.sk_tiles;
+      while (n > 1) {
+        const int stride = (n + 63) / 64;
+        const int probe = lo + (int)threadIdx.x * stride;
+        const bool le = probe < lo + n && a.sk_pref[probe] * nch <= sk_u;
+        const int cnt = __popcll(__ballot(le));
+        const int nlo = lo + max(cnt - 1, 0) * stride;
+        n = min(stride, lo + n - nlo);
+        lo = nlo;
+      }
+      if (threadIdx.x == 0) s_tile[0] = lo;
+    }
+    __syncthreads();
+    sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);
+  }
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wpack), 0, 0x7FFFFFFF, kRsrcFlags);
+  const uint32_t ld_bytes = (uint32_t)(a.x_ld * 4);
+  const int sk_total = SK ? sk_u1 - sk_u : 0;
+  int sk_done = 0, prio_qtr = -1;
+  for (;;) {  // one pass per tile piece (exactly one when !SK)
+  bool sk_whole = true;
+  int sk_next_u = 0, sk_c0 = 0, sk_steps = 0;
+  int t = threadIdx.x;
+  if constexpr (SK) asm volatile("" : "+v"(t));  // see spconv_mfma_kernel
+  const int lane = t & 63, wave = t >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  if constexpr (SK) {
+    const int64_t row0 = (int64_t)sk_tile * TM;
+    const uint32_t tmask = a.sk_mask[sk_tile];
+    const int pref = a.sk_pref[sk_tile] * nch, ns_t = __popc(tmask) * nch;
+    const int jb = sk_u - pref, je = min(sk_u1 - pref, ns_t);
+    sk_whole = (jb == 0 && je == ns_t);
+    sk_next_u = pref + je;
+    const int o0 = jb / nch, o1 = (je - 1) / nch;
+    sk_c0 = jb - o0 * nch;
+    sk_steps = je - jb;
+    if (t < a.K && ((tmask >> t) & 1u)) {
+      const int j = __popc(tmask & ((1u << t) - 1u));
+      if (j >= o0 && j <= o1) {
+        s_kabs[j - o0] = t;
+        s_kmeta[j - o0] = make_int2(j - o0, (int)((uint32_t)a.wsel[t] * wk_bytes + slice_bytes));
+      }
+    }
+    if (t == 0) s_nk = sk_steps > 0 ? o1 - o0 + 1 : 0;
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    __syncthreads();
+    const int cnt = sk_steps > 0 ? o1 - o0 + 1 : 0;
+    for (int p = t; p < cnt * TM; p += 256) {
+      const int q = p / TM, rr = p - q * TM;
+      const int64_t row = row0 + rr;
+      const int32_t v = row < a.n_rows ? a.nbr[(int64_t)s_kabs[q] * a.n_rows + row] : -1;
+      s_off[q][rr] = v >= 0 ? (uint32_t)v * ld_bytes : kAbsent;
+    }
+  } else {
+    int64_t tile = blockIdx.x;
+    if (a.xcd_tiles > 0) {
+      tile = (int64_t)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
+      if (tile * TM >= a.n_rows) return;
+    }
+    const int64_t row0 = tile * TM;
+    const int kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
+    const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
+    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
+    for (int p = t; p < (kend - kbeg) * TM; p += 256) {
+      const int q = p / TM, rr = p - q * TM;
+      const int64_t row = row0 + rr;
+      int32_t v = -1;
+      if (row < a.n_rows) v = a.nbr ? a.nbr[(int64_t)(kbeg + q) * a.n_rows + row] : (int32_t)row;
+      s_off[q][rr] = v >= 0 ? (uint32_t)v * ld_bytes : kAbsent;
+    }
+    __syncthreads();
+    if (t < 64) {  // offsets with at least one neighbour in this tile
+      int nk = 0;
+      for (int q = 0; q < kend - kbeg; ++q) {
+        bool any = false;
+        for (int rr = t; rr < TM; rr += 64) any |= (s_off[q][rr] != kAbsent);
+        if (__any(any)) {
+          if (t == 0) s_kmeta[nk] = make_int2(q, (int)((uint32_t)a.wsel[kbeg + q] * wk_bytes + slice_bytes));
+          ++nk;
+        }
+      }
+      if (t == 0) s_nk = nk;
+    }
+  }
+  __syncthreads();
+  const int nk = s_nk;
+  const int nsteps = SK ? sk_steps : nk * nch;
+
+  f32x4 acc[2][CTN];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int ct = 0; ct < CTN; ++ct) acc[g][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // this thread's pieces of a weight block (linear copy: piece p of the block -> s_b[buf][p]); DMA: per wave, 64 pieces
+  // = 1 KiB per instruction, wave w takes the wave-pieces w, w + 4, ...
+  constexpr int BRR = DMA ? 1 : BR;
+  uint32_t bvo[BRR];
+#pragma unroll
+  for (int q = 0; q < BRR; ++q) bvo[q] = (t + q * 256 < PIECES) ? (uint32_t)(t + q * 256) * 16u : kAbsent;
+  u32x4 breg[BRR];
+  auto store_b = [&](int buf) {
+    if constexpr (!DMA) {
+#pragma unroll
+      for (int q = 0; q < BR; ++q)
+        if ((q + 1) * 256 <= PIECES || t + q * 256 < PIECES) s_b[buf][t + q * 256] = breg[q];
+    }
+  };
+  constexpr int WPIECES = PIECES / 64, WR = (WPIECES + 3) / 4;  // wave-pieces of a block, rounds of a wave
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_b = [&](int buf, uint32_t soff) {
+    if constexpr (DMA) {
+#pragma unroll
+      for (int r = 0; r < WR; ++r) {
+        const int wp = wave_u + 4 * r;
+        if (wp < WPIECES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)&s_b[buf][wp * 64], 16,
+                                                   (uint32_t)lane * 16u,
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(soff + (uint32_t)wp * 1024u)), 0, 0);
+      }
+    }
+  };
+  // load side: the (offset, chunk) whose operands are being requested -- one step ahead of the MFMAs (spconv16p_kernel)
+  v4f a0[2][2], a1[2][2];
+  int va0 = 0, va1 = 0;
+  int lj = 0, lc = sk_c0 - 1;
+  int2 l_meta = make_int2(0, 0);
+  uint32_t l_voff[2] = {kAbsent, kAbsent};
+  const uint32_t off_lane = (uint32_t)(wave * 32 + i) * 4;
+  auto stage_meta = [&]() {
+    ++lc;
+    if (lc == nch) {
+      lc = 0;
+      ++lj;
+    }
+    lc = __builtin_amdgcn_readfirstlane(lc);
+    lj = __builtin_amdgcn_readfirstlane(lj);
+    l_meta = s_kmeta[min(lj, KSLOTS - 1)];
+  };
+  auto stage_b = [&](bool live, int nbuf) {  // nbuf: the LDS buffer the block is for (DMA)
+    const int krow = __builtin_amdgcn_readfirstlane(l_meta.x) & 31;
+    const uint32_t wofs = (uint32_t)__builtin_amdgcn_readfirstlane(l_meta.y);
+    const char* row = reinterpret_cast<const char*>(&s_off[0][0]) + min(krow, KSLOTS - 1) * (TM * 4) + off_lane;
+    l_voff[0] = *reinterpret_cast<const uint32_t*>(row);
+    l_voff[1] = *reinterpret_cast<const uint32_t*>(row + 64);
+    const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wofs + (uint32_t)lc * chunk_bytes));
+    if constexpr (DMA) {
+      if (live) dma_b(nbuf, soff);
+    } else {
+#pragma unroll
+      for (int q = 0; q < BR; ++q)
+        breg[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, live ? bvo[q] : kAbsent, live ? soff : 0u, 0));
+    }
+  };
+  auto stage_a = [&](v4f (&dst)[2][2], bool live) -> int {
+    const uint32_t v0 = live ? l_voff[0] : kAbsent, v1 = live ? l_voff[1] : kAbsent;
+    const int va = (__any(v0 != kAbsent) ? 1 : 0) | (__any(v1 != kAbsent) ? 2 : 0);
+    const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(lc * (kKC * 4));
+    const uint32_t o0 = v0 + 16 * kk, o1 = v1 + 16 * kk;  // absent stays out of range
+    dst[0][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0, soff, 0));
+    dst[1][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1, soff, 0));
+    dst[0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0 + 64, soff, 0));
+    dst[1][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1 + 64, soff, 0));
+    return va;
+  };
+
+  if (nsteps > 0) {
+    stage_meta();
+    stage_b(true, 0);
+    va0 = stage_a(a0, true);
+    store_b(0);
+    __syncthreads();  // (DMA: the barrier's fence waits for the block to have landed)
+    auto do_step = [&](int step, v4f (&cur)[2][2], int va_cur, v4f (&nxt)[2][2], int& va_nxt) {
+      const bool more = step + 1 < nsteps;
+      if constexpr (SK) {  // issue priority falls with the workgroup's progress through its share (spconv16p_kernel)
+        const int qtr = __builtin_amdgcn_readfirstlane(((sk_done + step) * 4) / max(sk_total, 1));
+        if (qtr != prio_qtr) {
+          prio_qtr = qtr;
+          if (qtr <= 0) __builtin_amdgcn_s_setprio(3);
+          else if (qtr == 1) __builtin_amdgcn_s_setprio(2);
+          else if (qtr == 2) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      const bool g0 = (va_cur & 1) != 0, g1 = (va_cur & 2) != 0;
+      // the gathered rows of this step as three bf16 terms
+      u32x4 ah[2], am[2], al[2];
+      if (g0) split3(cur[0][0], cur[0][1], ah[0], am[0], al[0]);
+      if (g1) split3(cur[1][0], cur[1][1], ah[1], am[1], al[1]);
+      // B fragments of column tile ct: piece (term, n = 16 ct + i, kk); a two-tile register ring, read one tile ahead
+      const u32x4* sb = &s_b[step & 1][i * 4 + kk];
+      u32x4 bh[2], bm[2], bl[2];
+      if (va_cur) {
+        bh[0] = sb[0 * NS * 4];
+        bm[0] = sb[1 * NS * 4];
+        bl[0] = sb[2 * NS * 4];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < CTN; ++ct) {
+        const int rb = ct & 1;
+        if (va_cur && ct + 1 < CTN) {
+          bh[rb ^ 1] = sb[(0 * NS + 16 * (ct + 1)) * 4];
+          bm[rb ^ 1] = sb[(1 * NS + 16 * (ct + 1)) * 4];
+          bl[rb ^ 1] = sb[(2 * NS + 16 * (ct + 1)) * 4];
+        }
+        // six products, the small ones first.  One wave-uniform branch per column tile (not per MFMA); with both row
+        // groups present their MFMAs alternate (independent accumulators).
+#define PCMI_X3_MFMA(G, AT, BT)                                                                                             \
+  acc[G][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[G]), __builtin_bit_cast(bf16x8, BT[rb]), \
+                                                       acc[G][ct], 0, 0, 0)
+#define PCMI_X3_SIX(G)      \
+  PCMI_X3_MFMA(G, al, bh);  \
+  PCMI_X3_MFMA(G, ah, bl);  \
+  PCMI_X3_MFMA(G, am, bm);  \
+  PCMI_X3_MFMA(G, am, bh);  \
+  PCMI_X3_MFMA(G, ah, bm);  \
+  PCMI_X3_MFMA(G, ah, bh)
+        if (g0 && g1) {
+          PCMI_X3_MFMA(0, al, bh);
+          PCMI_X3_MFMA(1, al, bh);
+          PCMI_X3_MFMA(0, ah, bl);
+          PCMI_X3_MFMA(1, ah, bl);
+          PCMI_X3_MFMA(0, am, bm);
+          PCMI_X3_MFMA(1, am, bm);
+          PCMI_X3_MFMA(0, am, bh);
+          PCMI_X3_MFMA(1, am, bh);
+          PCMI_X3_MFMA(0, ah, bm);
+          PCMI_X3_MFMA(1, ah, bm);
+          PCMI_X3_MFMA(0, ah, bh);
+          PCMI_X3_MFMA(1, ah, bh);
+        } else if (g0) {
+          PCMI_X3_SIX(0);
+        } else if (g1) {
+          PCMI_X3_SIX(1);
+        }
+#undef PCMI_X3_SIX
+#undef PCMI_X3_MFMA
+        // the next step's operands, requested in the shadow of this step's MFMAs
+        if (ct == 0) stage_meta();
+        if (ct == 1) stage_b(more, (step + 1) & 1);
+        if (ct == 2) va_nxt = stage_a(nxt, more);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) store_b((step + 1) & 1);
+      __syncthreads();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+      do_step(step, a0, va0, a1, va1);
+      if (step + 1 < nsteps) do_step(step + 1, a1, va1, a0, va0);
+    }
+  }
+
+  // ---- epilogue: D[row = 4 kk + r][col = i] of every 16x16 tile --------------------------------------------------
+  if (SK && !sk_whole) {
+    float* pp = a.sk_part + ((int64_t)(2 * sk_g + (sk_first ? 0 : 1)) * TM + wave * 32) * a.N + n0 + i;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = g * 16 + 4 * kk + r;
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) pp[(int64_t)rl * a.N + ct * 16] = acc[g][ct][r];
+      }
+  } else {
+    float* outp = a.out + (int64_t)blockIdx.z * a.split_stride;
+    float bv[CTN];
+#pragma unroll
+    for (int ct = 0; ct < CTN; ++ct) bv[ct] = a.bias ? a.bias[n0 + ct * 16 + i] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int32_t orow = s_orow[wave * 32 + g * 16 + 4 * kk + r];
+        if (orow >= 0) {
+          float* op = outp + (int64_t)orow * a.out_ld + n0 + i;
+          if (a.accumulate) {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] += acc[g][ct][r] + bv[ct];
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] = acc[g][ct][r] + bv[ct];
+          }
+        }
+      }
+  }
+  if constexpr (!SK) {
+    break;
+  } else {
+    sk_u = sk_next_u;
+    ++sk_tile;
+    sk_first = false;
+    sk_done += nsteps;
+    if (sk_u >= sk_u1) break;
+    __syncthreads();  // s_off / s_orow / the staging area are rewritten by the next piece
+  }
+  }  // for (;;)
+}
+
+template <bool SK, bool DMA>
+int launch_x3(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  switch (NT) {
+    case 2: spconv16x_kernel<2, SK, DMA><<<grid, 256, 0, st>>>(a); break;
+    case 3: spconv16x_kernel<3, SK, DMA><<<grid, 256, 0, st>>>(a); break;
+    case 4: spconv16x_kernel<4, SK, DMA><<<grid, 256, 0, st>>>(a); break;
+    default: set_error("spconv x3: bad NT %d", NT); return PCMI_ERR_INVALID;
+  }
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+// PCMI_X3_DMA=0: weight blocks through staging registers instead of global -> LDS loads (A/B and the parity test)
+bool x3_dma() {
+  const char* e = getenv("PCMI_X3_DMA");
+  return !e || atoi(e) != 0;
+}
+
+}  // namespace
+
+size_t x3_pack_bytes(int K, int C, int N) { return align_up((size_t)std::max(K, 1) * C * N * 6, 256); }
+
+int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st) {
+  PCMI_REQUIRE(out && ((uintptr_t)out % 16 == 0) && a.C % kKC == 0 && a.N % (32 * NT) == 0, PCMI_ERR_INVALID,
+               "spconv x3: bad pack arguments (%d -> %d, NT %d)", a.C, a.N, NT);
+  // every weight slice a launch can select: wsel maps offsets to slices 0 .. K-1
+  const int64_t total = (int64_t)a.K * (a.C / kKC) * a.N * 4;
+  x3_pack_kernel<<<dim3((unsigned)ceil_div(total, 256)), 256, 0, st>>>(a.w, a.w_kstride, a.w_sc, a.w_sn, a.K, a.C, a.N, 32 * NT,
+                                                                      reinterpret_cast<u32x4*>(out));
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st) {
+  PCMI_REQUIRE(a.wpack && NT >= 2 && NT <= 4, PCMI_ERR_INVALID, "spconv x3: needs packed weights and NT in 2..4 (NT %d)", NT);
+  if (x3_dma()) return sk ? launch_x3<true, true>(NT, a, grid, st) : launch_x3<false, true>(NT, a, grid, st);
+  return sk ? launch_x3<true, false>(NT, a, grid, st) : launch_x3<false, false>(NT, a, grid, st);
+}
+
+}  // namespace pcmi

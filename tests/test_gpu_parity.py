@@ -961,6 +961,71 @@ def test_conv16_pipelined_matches_unpipelined(ME, size, cin, cout, monkeypatch):
       assert_close(res["1"][1], res["0"][1], 1e-5, "backward-data, unit-balanced")
 
 
+def _fp64_conv(cm, m, x, W):
+  """sum_k x[nbr_k] @ W[k] in float64 on the device (absent neighbours contribute nothing)."""
+  nbr = cm.export_map(m)[0].long()
+  y = torch.zeros(x.shape[0], W.shape[2], dtype=torch.float64, device=x.device)
+  xd, Wd = x.double(), W.double()
+  for k in range(W.shape[0]):
+    idx = nbr[k]
+    ok = idx >= 0
+    y[ok] += xd[idx[ok]] @ Wd[k]
+  return y
+
+
+@pytest.mark.parametrize("dma", ["1", "0"])
+@pytest.mark.parametrize("size,cin,cout", [("mid", 64, 64), ("large", 96, 96), ("large", 128, 96), ("large", 64, 128),
+                                           ("mid", 256, 256), ("large", 192, 128)])
+def test_conv16_x3_split_precision_matches_fp32(ME, size, cin, cout, dma, monkeypatch):
+  """spconv16x_kernel (csrc/spconv_x3.hip, PCMI_CONV16_X3=1: fp32 operands as three bf16 terms each, six
+  v_mfma_f32_16x16x32_bf16 per tile instead of eight v_mfma_f32_16x16x4_f32) against the fp32-MFMA kernel and against a
+  float64 contraction: forward and backward-data, whole-tile and unit-balanced launches, weight blocks by global->LDS
+  loads (PCMI_X3_DMA=1) and through registers.  The split form must be as close to float64 as the fp32 kernel is (both
+  are fp32-round-off class: ~1e-6 of the largest output) -- far inside the north_star's 1e-4."""
+  import json
+  from pointcontrast_amd import functional as PF
+  C = _coords(size)
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  torch.manual_seed(4)
+  W = (torch.randn(27, cin, cout, device=DEV) / (cin * 27) ** 0.5).requires_grad_(True)
+  b = torch.randn(cout, device=DEV)
+  g = torch.randn(len(C), cout, device=DEV)
+  x0 = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+  # operands with a wide dynamic range: a bf16-only contraction would be off by 4e-3 here
+  x0 = x0 * torch.exp(torch.randn(len(C), 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6)))
+  y64 = _fp64_conv(cm, m, x0, W.detach()) + b.double()
+  mirror = [int(m.mirror[k]) for k in range(27)]
+  g64 = _fp64_conv(cm, m, g, W.detach()[mirror].transpose(1, 2))  # gin[i] = sum_k gout[nbr_k(i)] @ W[mirror(k)]^T
+  monkeypatch.setenv("PCMI_CONV16", "1")
+  monkeypatch.setenv("PCMI_X3_DMA", dma)
+  report = {}
+  for sk in ("16", "0"):
+    monkeypatch.setenv("PCMI_SPCONV_STREAMK", sk)
+    res = {}
+    for mode in ("0", "1"):
+      monkeypatch.setenv("PCMI_CONV16_X3", mode)
+      x = x0.clone().requires_grad_(True)
+      y = PF.SparseConvFunction.apply(x, W, b, m, False, len(C), cm)
+      y.backward(g)
+      torch.cuda.synchronize()
+      res[mode] = (y.detach().clone(), x.grad.clone())
+    e = {"fwd_fp32": rel_err(res["0"][0], y64), "fwd_x3": rel_err(res["1"][0], y64),
+         "bwd_fp32": rel_err(res["0"][1], g64), "bwd_x3": rel_err(res["1"][1], g64),
+         "fwd_x3_vs_fp32": rel_err(res["1"][0], res["0"][0]), "bwd_x3_vs_fp32": rel_err(res["1"][1], res["0"][1])}
+    report["streamk=" + sk] = e
+    what = "%s %d->%d sk=%s dma=%s: %s" % (size, cin, cout, sk, dma, json.dumps({k: "%.2e" % v for k, v in e.items()}))
+    assert e["fwd_fp32"] <= 1e-5 and e["bwd_fp32"] <= 1e-5, "fp32 kernel vs float64: " + what
+    assert e["fwd_x3"] <= max(4 * e["fwd_fp32"], 2e-6), "split-precision forward vs float64: " + what
+    assert e["bwd_x3"] <= max(4 * e["bwd_fp32"], 2e-6), "split-precision backward-data vs float64: " + what
+  out_dir = os.environ.get("PCMI_X3_REPORT_DIR")
+  if out_dir:
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "x3_err_%s_%d_%d_dma%s.json" % (size, cin, cout, dma)), "w") as f:
+      json.dump(report, f)
+
+
 @pytest.mark.parametrize("size,cin,cout", [("small", 64, 96), ("mid", 128, 32), ("large", 96, 96), ("tiny", 256, 256)])
 def test_wgrad_buffer_form_is_bit_identical(ME, size, cin, cout, monkeypatch):
   """wgrad_mfma_kernel<.., BUF = true> (32-bit byte offsets, raw buffer loads, the ragged last group of a wave padded
