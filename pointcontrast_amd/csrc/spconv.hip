@@ -1289,9 +1289,16 @@ static bool conv16_pipelined() {
 
 // PCMI_CONV16_X3=1: the split-precision form (spconv_x3.hip: fp32 operands as three bf16 terms on the bf16 matrix
 // cores) for the matrix-bound launches of the 16-row kernel (>= 64 channels on both sides).  Off by default.
-static bool conv16_x3(int NT, int C, int N) {
+static bool conv16_x3_on() {
   const char* e = getenv("PCMI_CONV16_X3");
-  return e && atoi(e) != 0 && NT >= 2 && NT <= 4 && C >= 64 && N >= 64;
+  return e && atoi(e) != 0;
+}
+static bool conv16_x3(int NT, int C, int N) { return conv16_x3_on() && NT >= 2 && NT <= 4 && C >= 64 && N >= 64; }
+// PCMI_X3_MAXNT=2: 128-wide outputs as two 64-wide slices (NT = 4 holds two weight blocks of 24 KiB in LDS and 190+
+// registers: 2 waves per SIMD; two NT = 2 slices gather and split the rows twice but run 3 waves per SIMD)
+static int x3_max_nt() {
+  const char* e = getenv("PCMI_X3_MAXNT");
+  return e ? atoi(e) : 4;
 }
 // resident workgroups per CU of spconv16x_kernel (LDS: 2 weight blocks of 6 KiB x NT + the 13.5 KiB offset table)
 static int x3_workgroups(int NT) { return (NT <= 3 ? 3 : 2) * num_cu() / 8 * 8; }
@@ -1475,6 +1482,7 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     a.perm = map->perm;
   }
   Plan p = make_plan(n_rows, N, a.K, false);
+  if (p.NT == 4 && p.RW == 4 && conv16_x3_on() && x3_max_nt() < 4 && C >= 64) p.NT = 2;
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
       map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64) {
