@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 
 
 def get_batch(seed, batch_size, voxel_size):
@@ -67,6 +68,11 @@ def level1_tensor(batch, device, joint=True):
   st = ME.SparseTensor(torch.cat([batch["sinput0_F"], batch["sinput1_F"]]), coords=torch.cat([C0, C1])).to(device)
   st.coords_man.set_split(C0.shape[0])
   return st
+
+
+def _split_precision():
+  from pointcontrast_amd._lib import lib
+  return bool(lib.pcmi_spconv_split_precision())
 
 
 def conv_work(model):
@@ -124,6 +130,7 @@ def kernel_rooflines(batch, device, joint=True):
   n = st.F.shape[0]
   m = cm.kernel_map(key, key, 3, 1, 3)
   out = []
+  x3_on = bool(lib.pcmi_spconv_split_precision())
 
   def conv_entry(label, cin, cout, kmap, K, n_in, n_out, transpose=False, mode="fwd"):
     W = torch.randn((K, cin, cout) if K > 1 else (cin, cout), device=device) * 0.05
@@ -154,7 +161,17 @@ def kernel_rooflines(batch, device, joint=True):
     bound = "mfma" if intensity > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
     ent = {"kernel": label, "ms": round(t * 1e3, 4), "pairs": int(M), "gflop": round(flops * 1e-9, 3),
            "algo_mb": round(byts * 1e-6, 2), "bound": bound}
-    if bound == "mfma":
+    # which launches the split-precision kernel takes (csrc/spconv.hip: run_gathered): 3^3 / 2^3 table launches of the
+    # 16-row kernel with >= 64 channels on both sides -- forward and backward-data, not the weight gradients
+    split = (x3_on and mode in ("fwd", "bwd_data") and kmap is not None and min(cin, cout) >= 64 and not transpose
+             and min(n_in, n_out) >= 8192)
+    if bound == "mfma" and split:
+      # fp32 products from six bf16 MFMAs: the matrix-pipe bound of THIS arithmetic is the dense bf16 peak / 6; the
+      # fraction of the fp32 instruction's own peak is given beside it (it can exceed 1: that is the point of the split)
+      ent.update(achieved=round(flops / t * 1e-12, 3), peak=round(PEAK_BF16_MFMA_TFLOPS / 6, 1), unit="TFLOP/s",
+                 arithmetic="fp32 operands as 3 bf16 terms, 6 v_mfma_f32_16x16x32_bf16 per fp32-equivalent tile, fp32 accumulate",
+                 peak_fp32_mfma=PEAK_FP32_MFMA_TFLOPS, frac_of_fp32_mfma_peak=round(flops / t * 1e-12 / PEAK_FP32_MFMA_TFLOPS, 4))
+    elif bound == "mfma":
       ent.update(achieved=round(flops / t * 1e-12, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s")
     else:
       ent.update(achieved=round(byts / t * 1e-9, 1), peak=PEAK_HBM_GBS, unit="GB/s")
@@ -162,10 +179,11 @@ def kernel_rooflines(batch, device, joint=True):
     out.append(ent)
     return ent
 
-  dominant = conv_entry("spconv16p fwd 3^3 96->96 @level1 (%d rows)" % n, 96, 96, m, 27, n, n)
-  conv_entry("spconv_mfma bwd_data 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_data")
-  conv_entry("wgrad_mfma 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
-  conv_entry("spconv_mfma fwd 3^3 128->96 @level1", 128, 96, m, 27, n, n)
+  kname = "spconv16x (bf16x3 split)" if x3_on else "spconv16p (fp32 MFMA)"
+  dominant = conv_entry("%s fwd 3^3 96->96 @level1 (%d rows)" % (kname, n), 96, 96, m, 27, n, n)
+  conv_entry("%s bwd_data 3^3 96->96 @level1" % kname, 96, 96, m, 27, n, n, mode="bwd_data")
+  conv_entry("wgrad_mfma (fp32 MFMA) 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
+  conv_entry("%s fwd 3^3 128->96 @level1" % kname, 128, 96, m, 27, n, n)
   ck = cm.stride(key, 2)
   m2 = cm.kernel_map(key, ck, 2, 2, 0)
   conv_entry("spconv_mfma fwd 2^3/s2 32->32 (gather)", 32, 32, m2, 8, m2.n_in, m2.n_out)
@@ -362,6 +380,10 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "engine": args.engine,
                    "pair_execution": ("one two-segment pass (BatchNorm statistics per cloud)"
                                       if args.engine == "native" and cfg.misc.get("joint_pair", True) else "one pass per cloud"),
+                   "conv_arithmetic": ("fp32 in / fp32 out; matrix-bound forward / backward-data convolutions contract fp32 operands "
+                                       "split into 3 bf16 terms on the bf16 matrix cores with fp32 accumulation (within fp32 "
+                                       "round-off of the fp32 instruction); everything else fp32 MFMA / VALU"
+                                       if _split_precision() else "fp32 MFMA / VALU throughout"),
                    "final_loss": round(loss_val, 5),
                    "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),
@@ -394,8 +416,16 @@ def main():
           per_launch = json.load(f)["bytes_per_launch"]
         # the unit-balanced launch of this conv = main kernel + fix-up kernel (in pmc_probe.py only the 96->96 conv
         # takes that launch, so the fix-up's per-launch average belongs to this shape)
-        for name in ("spconv16p_kernel<3, false, true>", "spconv16_kernel<3, false, true>",
-                     "spconv_mfma_kernel<3, 4, false, false, true, 32, 256>"):
+        # (the pmc file also says which level-1 tensor it was collected on: a count of pairs other than this run's
+        #  means a stale file, and the traffic is then not reported)
+        if dom["kernel"].startswith("spconv16x"):
+          names = ("spconv16x_kernel<3, true, true>",)
+        else:
+          names = ("spconv16p_kernel<3, false, true>", "spconv16_kernel<3, false, true>",
+                   "spconv_mfma_kernel<3, 4, false, false, true, 32, 256>")
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+          same_shape = json.load(f).get("algorithmic", {}).get("96->96", {}).get("pairs") == dom["pairs"]
+        for name in names if same_shape else ():
           if name in per_launch:
             traffic = per_launch[name] + per_launch.get("sk_fixup_kernel", 0.0)
             break
@@ -403,7 +433,8 @@ def main():
         pass
       out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
                          "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (PMC, calibrated)",
-                         "kernel": dom["kernel"], "ms": dom["ms"]}
+                         "kernel": dom["kernel"], "ms": dom["ms"],
+                         **{k: dom[k] for k in ("arithmetic", "peak_fp32_mfma", "frac_of_fp32_mfma_peak") if k in dom}}
       out["kernels"] = kernels
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = run_cpu_baseline_bounded()

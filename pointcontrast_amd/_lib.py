@@ -84,6 +84,7 @@ PROTOTYPES = {
                                        c_i64, c_vp, c_sz, c_vp]),
     "pcmi_spconv_bwd_weight": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, c_i64, c_i64, C.c_int, _KP, C.c_int,
                                          c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "pcmi_spconv_split_precision": (C.c_int, []),
     "pcmi_bn_workspace_bytes": (c_sz, [c_i64, C.c_int]),
     "pcmi_bn_fwd_train": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp,
                                     c_i64, C.c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -1287,11 +1287,11 @@ static bool conv16_pipelined() {
   return !e || atoi(e) != 0;
 }
 
-// PCMI_CONV16_X3=1: the split-precision form (spconv_x3.hip: fp32 operands as three bf16 terms on the bf16 matrix
-// cores) for the matrix-bound launches of the 16-row kernel (>= 64 channels on both sides).  Off by default.
+// The split-precision form (spconv_x3.hip: fp32 operands as three bf16 terms on the bf16 matrix cores) takes the
+// matrix-bound launches of the 16-row kernel (>= 64 channels on both sides); PCMI_CONV16_X3=0: the fp32-MFMA kernel.
 static bool conv16_x3_on() {
   const char* e = getenv("PCMI_CONV16_X3");
-  return e && atoi(e) != 0;
+  return !e || atoi(e) != 0;
 }
 static bool conv16_x3(int NT, int C, int N) { return conv16_x3_on() && NT >= 2 && NT <= 4 && C >= 64 && N >= 64; }
 // PCMI_X3_MAXNT=2: 128-wide outputs as two 64-wide slices (NT = 4 holds two weight blocks of 24 KiB in LDS and 190+
@@ -1652,6 +1652,8 @@ int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int 
   return spconv_backward_data(gout, gout_ld, n_out, cout, weight, cin, map, transpose, gin, gin_ld, n_in, 0, ws,
                               ws_bytes, as_stream(stream));
 }
+
+int pcmi_spconv_split_precision(void) { return conv16_x3_on() ? 1 : 0; }
 
 #if PCMI_ABLATE == 9
 int pcmi_debug_conv_prof(unsigned long long* host_out) {

@@ -23,7 +23,10 @@
 //   * v_mfma_f32_16x16x32_bf16: lane (i = l & 15, kk = l >> 4) supplies A[i][8 kk .. 8 kk + 7] and B[8 kk ..][j = i];
 //     which eight channels those are is free as long as A and B agree: channel(kk, e) = 4 kk + (e & 3) + 16 (e >> 2)
 //     (the two float4 the lane gathers).  C/D layout as the fp32 16x16 form: D[row = 4 kk + r][col = i].
-// Opt-in (PCMI_CONV16_X3=1) until it has been through the whole GPU suite.
+// Default for the matrix-bound launches of the 16-row kernel (>= 64 channels on both sides); PCMI_CONV16_X3=0 restores
+// the fp32-MFMA kernel.  Measured (profiles/r02_x3_*): level-1 96->96 on the 175k-row pair tensor 0.530 -> 0.343 ms
+// (161 TFLOP/s of fp32-equivalent work: above the 157.3 TFLOP/s peak of the fp32 instruction), 128->128 at level 2
+// 0.341 -> 0.170 ms; max |difference| to the fp32 kernel 0.9-2.9e-6 of the largest output.
 #include <algorithm>
 #include <cstdlib>
 
@@ -32,8 +35,6 @@
 #include "spconv_args.h"
 
 namespace pcmi {
-
-namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
 }
 
 template <bool SK, bool DMA>
-int launch_x3(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
+static int launch_x3(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
   switch (NT) {
     case 2: spconv16x_kernel<2, SK, DMA><<<grid, 256, 0, st>>>(a); break;
     case 3: spconv16x_kernel<3, SK, DMA><<<grid, 256, 0, st>>>(a); break;
@@ -450,12 +451,10 @@ int launch_x3(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // PCMI_X3_DMA=0: weight blocks through staging registers instead of global -> LDS loads (A/B and the parity test)
-bool x3_dma() {
+static bool x3_dma() {
   const char* e = getenv("PCMI_X3_DMA");
   return !e || atoi(e) != 0;
 }
-
-}  // namespace
 
 size_t x3_pack_bytes(int K, int C, int N) { return align_up((size_t)std::max(K, 1) * C * N * 6, 256); }
 

@@ -36,7 +36,7 @@ for line in open(os.path.join(src, "pmc_FETCH_SIZE.log")):
     algo[line.split()[2]] = {k: int(v) for k, v in m.items()}
 rows, traffic = [], {}
 for k in F:
-  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "sk_fixup", "eltwise_kernel<2>")):
+  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "sk_fixup", "x3_pack", "eltwise_kernel<2>")):
     continue
   rd = mean(F[k]["FETCH_SIZE"]) * 1024 * f_scale
   wr = mean(W[k]["WRITE_SIZE"]) * 1024 * w_scale if k in W else float("nan")
@@ -46,6 +46,8 @@ for k in F:
     gui = mean(M[k]["GRBM_GUI_ACTIVE"]) / 8.0  # summed over the 8 XCDs
     util = mean(M[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0 / gui  # per SIMD (256 CUs x 4)
     mops = mean(M[k]["SQ_INSTS_VALU_MFMA_MOPS_F32"]) * 512 * 1e-9
+    if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in M[k]:  # the split-precision kernel: bf16 MFMA work (six products per fp32 product)
+      mops += mean(M[k]["SQ_INSTS_VALU_MFMA_MOPS_BF16"]) * 512 * 1e-9
   rows.append((k.split("(")[0], len(F[k]["FETCH_SIZE"]), us, rd * 1e-6, wr * 1e-6, util, mops))
   traffic[k.split("(")[0]] = rd + wr
 md = ["# PMC summary (%s): rocprofv3 --kernel-trace --pmc <counter> -- python scripts/pmc_probe.py" % tag, "",
@@ -56,7 +58,7 @@ md = ["# PMC summary (%s): rocprofv3 --kernel-trace --pmc <counter> -- python sc
 for r in rows:
   md.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f %% | %.2f |" % (r[0], r[1], r[2], r[3], r[4], 100 * r[5], r[6]))
 md += ["", "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); issued GFLOP = "
-       "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 (compare with the algorithmic 2*M*Cin*Cout: the excess is MFMA work on absent neighbours)."]
+       "(SQ_INSTS_VALU_MFMA_MOPS_F32 + ..._BF16) x 512 (the split-precision kernel issues 6 bf16 products per fp32 product; compare with the algorithmic 2*M*Cin*Cout: the excess is MFMA work on absent neighbours)."]
 open(os.path.join(root, "profiles", "%s_pmc_summary.md" % tag), "w").write("\n".join(md) + "\n")
 json.dump({"source": "%s_pmc_summary.md" % tag, "bytes_per_launch": traffic, "algorithmic": algo},
           open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)

@@ -916,6 +916,7 @@ def test_conv16_matches_32row_kernel(ME, size, cin, cout, monkeypatch):
   b = torch.randn(cout, device=DEV)
   g = torch.randn(len(C), cout, device=DEV)
   res = {}
+  monkeypatch.setenv("PCMI_CONV16_X3", "0")  # fp32-MFMA kernels on both sides (the split-precision kernel has its own test)
   for mode in ("0", "1"):
     monkeypatch.setenv("PCMI_CONV16", mode)
     x = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
@@ -943,6 +944,7 @@ def test_conv16_pipelined_matches_unpipelined(ME, size, cin, cout, monkeypatch):
   b = torch.randn(cout, device=DEV)
   g = torch.randn(len(C), cout, device=DEV)
   monkeypatch.setenv("PCMI_CONV16", "1")
+  monkeypatch.setenv("PCMI_CONV16_X3", "0")  # the two fp32-MFMA forms (the split-precision kernel has its own test)
   for sk in ("16", "0"):
     monkeypatch.setenv("PCMI_SPCONV_STREAMK", sk)
     res = {}
