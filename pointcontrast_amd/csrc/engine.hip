@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "spconv_args.h"
 
 namespace pcmi {
 
@@ -135,6 +136,13 @@ struct pcmi_net {
   hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_switch = nullptr;
   pcmi::DevBuf ws_side[2];
   pcmi::DevBuf grads_peer;
+  // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
+  // top of a forward pass (x3_prepack) instead of one pack launch in front of every convolution
+  pcmi::DevBuf x3_packs, x3_jobs_dev;
+  std::vector<pcmi::X3Prepacked> x3_table;
+  const float* x3_params = nullptr;
+  int x3_n_jobs = 0;
+  int64_t x3_items = 0;
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
   ~pcmi_net() {
     (void)hipDeviceSynchronize();
@@ -192,6 +200,86 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
   if (op.type == PCMI_OP_BN) return pcmi_bn_workspace_bytes(n_in, op.cout);
   return 0;
 }
+
+// Packs the weights of every layer the split-precision kernel can take (3^3 / 2^3 convolutions with >= 64 channels on
+// both sides), forward and backward-data orientation, in one launch on `st`, and makes the table current for this
+// thread's convolution calls.  The job table is built once per parameter buffer.  PCMI_X3_PREPACK=0: every convolution
+// packs its own weights in front of its launch (as the C-ABI entry points do).
+static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st) {
+  const char* pe = getenv("PCMI_X3_PREPACK");  // read per pass: the parity test runs both forms in one process
+  const bool enabled = !(pe && pe[0] == '0');
+  if (!enabled || !pcmi_spconv_split_precision()) {
+    x3_set_prepacked(nullptr, 0);
+    return PCMI_OK;
+  }
+  if (n.x3_params != params) {
+    std::vector<X3PackJob> jobs;
+    n.x3_table.clear();
+    size_t bytes = 0;
+    int64_t items = 0;
+    for (const auto& op : n.ops) {
+      if (op.type != PCMI_OP_CONV || op.kernel_size <= 1) continue;
+      const int K = op.kernel_size * op.kernel_size * op.kernel_size;
+      for (int tr = 0; tr < 2; ++tr) {  // 0: B = W[k] ([cin x cout]); 1: B = W[k]^T ([cout x cin])
+        const int C = tr ? op.cout : op.cin, N = tr ? op.cin : op.cout;
+        if (C % 32 != 0 || N % 32 != 0 || C < 64 || N < 64) continue;
+        const int NT = x3_nt_for(N);
+        if (NT < 2) continue;
+        X3PackJob j;
+        j.w = params + op.w_off;
+        j.w_kstride = (int64_t)op.cin * op.cout;
+        j.w_sc = tr ? 1 : op.cout;
+        j.w_sn = tr ? op.cout : 1;
+        j.K = K;
+        j.C = C;
+        j.N = N;
+        j.NS = 32 * NT;
+        j.out = (void*)bytes;  // offset for now
+        j.first_item = items;
+        jobs.push_back(j);
+        n.x3_table.push_back({j.w, tr, NT, (const void*)bytes});
+        bytes += x3_pack_bytes(K, C, N);
+        items += (int64_t)K * (C / 32) * N * 4;
+      }
+    }
+    n.x3_n_jobs = (int)jobs.size();
+    n.x3_items = items;
+    if (!jobs.empty()) {
+      int rc = n.x3_packs.reserve(bytes, st);
+      if (rc) return rc;
+      rc = n.x3_jobs_dev.reserve(jobs.size() * sizeof(X3PackJob), st);
+      if (rc) return rc;
+      for (size_t i = 0; i < jobs.size(); ++i) {
+        jobs[i].out = n.x3_packs.p + (size_t)jobs[i].out;
+        n.x3_table[i].pack = n.x3_packs.p + (size_t)n.x3_table[i].pack;
+      }
+      // (pageable source: the copy has left the host buffer when the call returns)
+      PCMI_HIP_CHECK(hipMemcpy(n.x3_jobs_dev.p, jobs.data(), jobs.size() * sizeof(X3PackJob), hipMemcpyHostToDevice));
+    }
+    n.x3_params = params;
+  }
+  if (n.x3_n_jobs == 0) {
+    x3_set_prepacked(nullptr, 0);
+    return PCMI_OK;
+  }
+  const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(n.x3_jobs_dev.p), n.x3_n_jobs, n.x3_items, st);
+  if (rc) return rc;
+  x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
+  return PCMI_OK;
+}
+
+// Clears the calling thread's table of packed weights on scope exit.  The backward form first makes the packs of the
+// last forward pass current again: they are those of `params` as long as the weights have not been touched since (a
+// backward pass differentiates the forward pass that produced them, so they have not).
+struct X3TableScope {
+  X3TableScope() = default;
+  X3TableScope(const pcmi_net& n, const float* params) {
+    if (n.x3_n_jobs > 0 && n.x3_params == params) x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
+  }
+  X3TableScope(const X3TableScope&) = delete;
+  X3TableScope& operator=(const X3TableScope&) = delete;
+  ~X3TableScope() { x3_set_prepacked(nullptr, 0); }
+};
 
 // ---- backward -----------------------------------------------------------------------------------------
 // One pass's backward is a chain (bwd-data -> BN-bwd -> ...) on a "chain" stream plus the weight gradients,
@@ -491,6 +579,7 @@ struct BackwardRun {
 
 static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params, float* grads,
                         const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready, void* ready_ctx) {
+  const X3TableScope x3_scope(n, params);
   BackwardRun r(n, job, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
   int rc = r.begin();
   for (int i = (int)n.ops.size() - 1; i >= 0 && !rc; --i) rc = r.step(i);
@@ -692,6 +781,9 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.out_feats = out_feats;
   ps.out_ld = out_ld;
   ps.coords = coords;
+  rc = x3_prepack(n, params, st);
+  const X3TableScope x3_scope;  // the table is this thread's only until the pass has been enqueued
+  if (rc) return rc;
   g_prof_fwd.lap(2);
   // ---- run --------------------------------------------------------------------------------------
   for (int i = 0; i < n_ops; ++i) {
@@ -796,6 +888,7 @@ int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, 
                "net_backward_pair: passes 0 and 1 need a training-mode forward each");
   pcmi_net& n = *net;
   hipStream_t st = as_stream(stream);
+  const X3TableScope x3_scope(n, params);
   int rc = ensure_streams(n);
   if (rc) return rc;
   if (!n.chain1) PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.chain1, hipStreamNonBlocking));  // only if ever used

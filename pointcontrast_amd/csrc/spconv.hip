@@ -1300,6 +1300,15 @@ static int x3_max_nt() {
   const char* e = getenv("PCMI_X3_MAXNT");
   return e ? atoi(e) : 4;
 }
+// slice width of the 128-row launches of a level with >= 8192 rows (make_plan + the override above); the executor packs
+// the weights for exactly this width ahead of the launches
+int x3_nt_for(int N) {
+  if (N % 32 != 0 || !conv16_x3_on()) return 0;
+  const int nt_all = N / 32;
+  int nt = nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
+  if (nt == 4 && x3_max_nt() < 4) nt = 2;
+  return nt;
+}
 // resident workgroups per CU of spconv16x_kernel (LDS: 2 weight blocks of 6 KiB x NT + the 13.5 KiB offset table)
 static int x3_workgroups(int NT) { return (NT <= 3 ? 3 : 2) * num_cu() / 8 * 8; }
 
@@ -1499,8 +1508,12 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     dim3 grid((unsigned)G, (unsigned)(N / (32 * p.NT)), 1);
     int rc;
     if (x3) {
-      a.wpack = (char*)ws + part;
-      rc = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
+      a.wpack = x3_find_prepacked(w, w_transposed, p.NT);  // the executor's once-per-pass pack, if there is one
+      rc = PCMI_OK;
+      if (!a.wpack) {
+        a.wpack = (char*)ws + part;
+        rc = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
+      }
       if (rc == PCMI_OK) rc = x3_launch(p.NT, true, a, grid, st);
     } else if (c16)
       rc = w_transposed ? launch16<true, true>(p.NT, a, grid, st) : launch16<false, true>(p.NT, a, grid, st);
@@ -1518,9 +1531,12 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
   if (x3) {
     PCMI_REQUIRE(ws && ws_bytes >= split_bytes + x3_pack_bytes(a.K, C, N), PCMI_ERR_WORKSPACE,
                  "spconv: workspace %zu < %zu bytes", ws_bytes, split_bytes + x3_pack_bytes(a.K, C, N));
-    a.wpack = (char*)ws + split_bytes;
-    const int rc_pack = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
-    if (rc_pack) return rc_pack;
+    a.wpack = x3_find_prepacked(w, w_transposed, p.NT);
+    if (!a.wpack) {
+      a.wpack = (char*)ws + split_bytes;
+      const int rc_pack = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
+      if (rc_pack) return rc_pack;
+    }
   }
   if (p.ksplit > 1) {
     const size_t need = (size_t)p.ksplit * n_rows * N * sizeof(float);

@@ -43,5 +43,29 @@ size_t x3_pack_bytes(int K, int C, int N);
 int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st);
 // the 128-row-tile kernel itself (a.wpack set; grid as for spconv16p_kernel); NT in {2, 3, 4}
 int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st);
+// output slice width (in units of 32 channels) the 128-row launches use for N output channels; < 2: not eligible
+int x3_nt_for(int N);
+
+// ---- weights packed ahead of the launches (the network executor packs every eligible layer in ONE launch per forward
+// pass instead of one pack launch in front of every convolution) ----------------------------------------------------
+struct X3PackJob {   // one (layer, orientation): B_k[c][n] = w[k * w_kstride + c * w_sc + n * w_sn]
+  const float* w;
+  int64_t w_kstride, w_sc, w_sn;
+  int K, C, N, NS;
+  void* out;           // x3_pack_bytes(K, C, N)
+  int64_t first_item;  // exclusive prefix of K * (C / 32) * N * 4 over the jobs
+};
+int x3_pack_many(const X3PackJob* jobs_dev, int n_jobs, int64_t total_items, hipStream_t st);
+struct X3Prepacked {
+  const float* w;
+  int transposed;  // 0: B = W[k] (forward), 1: B = W[k]^T (backward-data)
+  int NT;
+  const void* pack;
+};
+// The calling thread's table of packed weights: run_gathered uses an entry instead of packing when (weights pointer,
+// orientation, slice width) match.  Set only while the owner guarantees the packs are current (the executor: from the
+// pack launch at the top of a forward pass to the end of the matching backward); nullptr / 0 clears.
+void x3_set_prepacked(const X3Prepacked* table, int n);
+const void* x3_find_prepacked(const float* w, bool transposed, int NT);
 
 }  // namespace pcmi

@@ -104,6 +104,41 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
 // DMA: the weight block of the next step goes global -> LDS directly (buffer_load_dwordx4 ... lds: the block is a
 // linear image, a wave instruction copies 1 KiB) instead of through 4 x BR staging registers per thread -- at NT = 3
 // that is what lets the kernel fit 3 waves per SIMD without spilling (185 -> 165 VGPRs).
+// The same for many (layer, orientation) jobs in one launch: a thread finds its job by bisection over the item prefix.
+__global__ __launch_bounds__(256) void x3_pack_many_kernel(const X3PackJob* __restrict__ jobs, int n_jobs, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {  // last job whose first item is <= idx
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_item <= idx) lo = mid; else hi = mid - 1;
+  }
+  const X3PackJob jb = jobs[lo];
+  const int64_t loc = idx - jb.first_item;
+  const int nch = jb.C / kKC, nns = jb.N / jb.NS;
+  const int kk = (int)(loc & 3);
+  int64_t r = loc >> 2;
+  const int nl = (int)(r % jb.NS);
+  r /= jb.NS;
+  const int ns = (int)(r % nns);
+  r /= nns;
+  const int cc = (int)(r % nch);
+  const int wk = (int)(r / nch);
+  const float* wb = jb.w + (int64_t)wk * jb.w_kstride + (int64_t)(ns * jb.NS + nl) * jb.w_sn;
+  v4f x0, x1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x0[e] = wb[(int64_t)(cc * kKC + x3_channel(kk, e)) * jb.w_sc];
+    x1[e] = wb[(int64_t)(cc * kKC + x3_channel(kk, e + 4)) * jb.w_sc];
+  }
+  u32x4 h, m, l;
+  split3(x0, x1, h, m, l);
+  u32x4* blk = reinterpret_cast<u32x4*>(jb.out) + (((int64_t)wk * nch + cc) * nns + ns) * (3 * jb.NS * 4);
+  blk[(0 * jb.NS + nl) * 4 + kk] = h;
+  blk[(1 * jb.NS + nl) * 4 + kk] = m;
+  blk[(2 * jb.NS + nl) * 4 + kk] = l;
+}
+
 template <int NT, bool SK, bool DMA>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArgs a) {
   constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
@@ -467,6 +502,25 @@ int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st) {
                                                                       reinterpret_cast<u32x4*>(out));
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
+}
+
+int x3_pack_many(const X3PackJob* jobs_dev, int n_jobs, int64_t total_items, hipStream_t st) {
+  if (n_jobs <= 0 || total_items <= 0) return PCMI_OK;
+  x3_pack_many_kernel<<<dim3((unsigned)ceil_div(total_items, 256)), 256, 0, st>>>(jobs_dev, n_jobs, total_items);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+static thread_local const X3Prepacked* t_prepacked = nullptr;
+static thread_local int t_n_prepacked = 0;
+void x3_set_prepacked(const X3Prepacked* table, int n) {
+  t_prepacked = table;
+  t_n_prepacked = table ? n : 0;
+}
+const void* x3_find_prepacked(const float* w, bool transposed, int NT) {
+  for (int i = 0; i < t_n_prepacked; ++i)
+    if (t_prepacked[i].w == w && (t_prepacked[i].transposed != 0) == transposed && t_prepacked[i].NT == NT) return t_prepacked[i].pack;
+  return nullptr;
 }
 
 int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st) {

@@ -1028,6 +1028,48 @@ def test_conv16_x3_split_precision_matches_fp32(ME, size, cin, cout, dma, monkey
       json.dump(report, f)
 
 
+def test_engine_prepacked_weights_are_bit_identical(ME, monkeypatch):
+  """The native executor packs the weights of every split-precision layer in ONE launch at the top of a forward pass
+  (engine.hip: x3_prepack; both orientations, read by the forward and the backward-data launches of that iteration)
+  instead of one pack launch in front of every convolution (PCMI_X3_PREPACK=0): same packed values, same kernels ->
+  identical features and parameter gradients, also after the weights have changed between two iterations."""
+  from pointcontrast_amd.engine import NativeEngine
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.distributed import FlatParameters
+  from pointcontrast_amd._lib import lib
+  assert lib.pcmi_spconv_split_precision() == 1
+  cfg = get_config([])
+  _, dev = _make_models("Res16UNet34C", cfg, seed=3)
+  dev.train()
+  flat = FlatParameters(dev.parameters())
+  eng = NativeEngine(dev, flat)
+  b = synthetic.make_batch(seed=6, batch_size=2, crop=0.9)
+  st = ME.SparseTensor(torch.from_numpy(b["sinput0_F"]), coords=torch.from_numpy(b["sinput0_C"])).to(DEV)
+  assert st.F.shape[0] >= 8192, "the level-1 convolutions must be on the 16-row kernels"
+  rs = {k: v.clone() for k, v in dev.state_dict().items() if "running" in k}
+  w0 = flat.w.clone()
+  res = {}
+  for mode in ("1", "0"):
+    monkeypatch.setenv("PCMI_X3_PREPACK", mode)
+    flat.w.copy_(w0)
+    dev.load_state_dict({**dev.state_dict(), **rs})
+    out = []
+    for it in range(2):  # second iteration: weights changed in place since the first pack
+      f = eng.forward(0, st)
+      g = torch.randn(f.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(11 + it))
+      flat.zero_grad()
+      eng.backward(0, g)
+      torch.cuda.synchronize()
+      out.append((f.detach().clone(), flat.g.clone()))
+      flat.w.add_(flat.g, alpha=-0.05)
+    res[mode] = out
+  for it in range(2):
+    assert torch.equal(res["1"][it][0], res["0"][it][0]), "features, iteration %d" % it
+    assert torch.equal(res["1"][it][1], res["0"][it][1]), "parameter gradients, iteration %d" % it
+  assert not torch.equal(res["1"][0][0], res["1"][1][0]), "the second iteration must see the updated weights"
+
+
 @pytest.mark.parametrize("size,cin,cout", [("small", 64, 96), ("mid", 128, 32), ("large", 96, 96), ("tiny", 256, 256)])
 def test_wgrad_buffer_form_is_bit_identical(ME, size, cin, cout, monkeypatch):
   """wgrad_mfma_kernel<.., BUF = true> (32-bit byte offsets, raw buffer loads, the ragged last group of a wave padded
