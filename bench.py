@@ -385,6 +385,7 @@ def main():
                                        "round-off of the fp32 instruction); everything else fp32 MFMA / VALU"
                                        if _split_precision() else "fp32 MFMA / VALU throughout"),
                    "final_loss": round(loss_val, 5),
+                   "host_cpu": getattr(os, "sched_getcpu", lambda: -1)(),
                    "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
                    **({"gpu_phase_ms_per_step": trainer.gpu_phase_ms(skip=args.warmup)} if trainer._gpu_marks else {}),
                    **({"forward_pair_ms": trainer.engine.pair_marks_ms(skip=args.warmup)}

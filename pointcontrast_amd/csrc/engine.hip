@@ -141,6 +141,7 @@ struct pcmi_net {
   pcmi::DevBuf x3_packs, x3_jobs_dev;
   std::vector<pcmi::X3Prepacked> x3_table;
   const float* x3_params = nullptr;
+  bool x3_current = false;  // the last forward pass packed (the packs are those of its weights)
   int x3_n_jobs = 0;
   int64_t x3_items = 0;
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
@@ -208,6 +209,7 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
 static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st) {
   const char* pe = getenv("PCMI_X3_PREPACK");  // read per pass: the parity test runs both forms in one process
   const bool enabled = !(pe && pe[0] == '0');
+  n.x3_current = false;
   if (!enabled || !pcmi_spconv_split_precision()) {
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
@@ -264,17 +266,19 @@ static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st) {
   }
   const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(n.x3_jobs_dev.p), n.x3_n_jobs, n.x3_items, st);
   if (rc) return rc;
+  n.x3_current = true;
   x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
   return PCMI_OK;
 }
 
 // Clears the calling thread's table of packed weights on scope exit.  The backward form first makes the packs of the
-// last forward pass current again: they are those of `params` as long as the weights have not been touched since (a
-// backward pass differentiates the forward pass that produced them, so they have not).
+// last forward pass current again -- if that pass packed at all (x3_current): they are those of `params` as long as the
+// weights have not been touched since (a backward pass differentiates the forward pass that produced them, so they
+// have not).
 struct X3TableScope {
   X3TableScope() = default;
   X3TableScope(const pcmi_net& n, const float* params) {
-    if (n.x3_n_jobs > 0 && n.x3_params == params) x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
+    if (n.x3_current && n.x3_n_jobs > 0 && n.x3_params == params) x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
   }
   X3TableScope(const X3TableScope&) = delete;
   X3TableScope& operator=(const X3TableScope&) = delete;

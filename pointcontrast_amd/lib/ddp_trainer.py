@@ -77,6 +77,11 @@ class ContrastiveLossTrainer:
     self.engine = None
     self.host_ms, self._host_t, self._host_c = {}, 0.0, 0.0
     self._prefetch_thread, self._prefetch_err = None, None
+    if config.misc.get("switch_interval", None):
+      # helper-thread experiments: CPython hands the GIL over every 5 ms by default, which is a third of an iteration --
+      # the enqueueing thread and the preparing thread then take turns at that granularity
+      import sys
+      sys.setswitchinterval(float(config.misc.switch_interval))
     self._gpu_marks = []
     if config.misc.get("engine", "native") == "native":
       from ..engine import NativeEngine
@@ -150,15 +155,23 @@ class ContrastiveLossTrainer:
       # forward / backward pass with half the launches and twice the rows per launch.  The reference calls its
       # network once per cloud (ddp_trainer.py:404-407); what differs between one call and two is only the BatchNorm
       # batch statistics, and the engine keeps those per segment (set_split).
+      sub = self._prep_mark  # misc.host_profile: where the preparation spends its host time
+      sub(None)
       C0, C1 = input_dict["sinput0_C"], input_dict["sinput1_C"]
       n_batch0 = int(C0[:, 0].max()) + 1 if C0.shape[0] else 0
       C1 = C1.clone()
       C1[:, 0] += n_batch0
-      sj = ME.SparseTensor(torch.cat([input_dict["sinput0_F"], input_dict["sinput1_F"]]),
-                           coords=torch.cat([C0, C1])).to(self.cur_device)
+      Cj, Fj = torch.cat([C0, C1]), torch.cat([input_dict["sinput0_F"], input_dict["sinput1_F"]])
+      sub("prep.concat")
+      sj = ME.SparseTensor(Fj, coords=Cj).to(self.cur_device)
       sj.coords_man.set_split(C0.shape[0])
+      sub("prep.upload_and_hash")
       sj.coords_man.plan_unet(self.engine.n_down)
+      sub("prep.levels_and_maps")
       prep = {"input": input_dict, "sj": sj, "n0": int(C0.shape[0])}
+      self._prepare_loss(prep, draws)
+      sub("prep.pair_selection")
+      return prep
     else:
       s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device)
       s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
@@ -171,6 +184,14 @@ class ContrastiveLossTrainer:
 
   def _prepare_loss(self, prep, draws):
     pass
+
+  def _prep_mark(self, phase):
+    if not self.config.misc.get("host_profile", False):
+      return
+    now = time.perf_counter()
+    if phase is not None:
+      self.host_ms[phase] = self.host_ms.get(phase, 0.0) + (now - self._prep_t) * 1e3
+    self._prep_t = now
 
   def _next_prepared(self, data_loader_iter, data_timer, draws):
     th = getattr(self, "_prefetch_thread", None)
@@ -413,21 +434,27 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     RNG on the host; the correspondences arrive on the host anyway, so the whole selection
     is host-side here (identical arithmetic: fp32 floor(u * count)) and only the two index
     vectors are uploaded."""
-    pp = pos_pairs.numpy() if torch.is_tensor(pos_pairs) else np.asarray(pos_pairs)
-    col0 = pp[:, 0].astype(np.int64, copy=False)
-    col1 = pp[:, 1].astype(np.int64, copy=False)
-    if len(col0) > 1 and (np.diff(col0) < 0).any():  # the loader's contract is "sorted by query row"
-      order = np.argsort(col0, kind="stable")
+    # ~840k correspondences per 4-pair batch, on the thread that enqueues the iteration (it was 3.8 ms of a 16.6 ms step
+    # as numpy passes over int64 copies): the two full-length passes are torch's threaded kernels on the int32 columns
+    # as they are; everything after the run starts works on the ~70k unique queries.
+    pp = pos_pairs if torch.is_tensor(pos_pairs) else torch.from_numpy(np.asarray(pos_pairs))
+    col0, col1 = pp[:, 0], pp[:, 1]
+    n = col0.shape[0]
+    if n > 1 and bool((col0[1:] < col0[:-1]).any()):  # the loader's contract is "sorted by query row"
+      order = torch.from_numpy(np.argsort(col0.numpy(), kind="stable"))
       col0, col1 = col0[order], col1[order]
-    # unique(return_counts=True) of a sorted column = its run starts / run lengths (single pass, no sort)
-    starts = np.flatnonzero(np.concatenate([[True], col0[1:] != col0[:-1]])) if len(col0) else np.zeros(0, np.int64)
-    count = torch.from_numpy(np.diff(np.concatenate([starts, [len(col0)]])).astype(np.int64))
-    q_unique = torch.from_numpy(col0[starts])
+    # unique(return_counts=True) of a sorted column = its run starts / run lengths (no sort)
+    starts = torch.zeros(min(n, 1), dtype=torch.int64)
+    if n > 1:
+      starts = torch.cat([starts, torch.nonzero(col0[1:] != col0[:-1]).squeeze(1) + 1])
+    count = torch.diff(starts, append=torch.tensor([n], dtype=torch.int64)) if n else starts
+    q_unique = col0[starts].long()
     draws = draws or {}
-    uniform = draws["uniform"] if "uniform" in draws else torch.distributions.Uniform(0, 1).sample([len(count)])
+    # (torch.distributions.Uniform(0, 1).sample([n]) of the reference IS torch.rand(n) * 1 + 0: same values, same
+    #  generator consumption, without building a distribution object per iteration)
+    uniform = draws["uniform"] if "uniform" in draws else torch.rand(len(count))
     off = torch.floor(torch.as_tensor(uniform, dtype=torch.float32) * count).long()
-    cums = torch.from_numpy(starts.astype(np.int64))  # exclusive cumsum of the counts
-    k_sel = torch.from_numpy(col1)[off + cums]
+    k_sel = col1[off + starts].long()  # starts = exclusive cumsum of the counts
     if npos < q_unique.shape[0]:
       si = draws["sampled_inds"] if "sampled_inds" in draws else np.random.choice(q_unique.shape[0], npos, replace=False)
       si = torch.as_tensor(np.asarray(si)).long()
