@@ -11,6 +11,7 @@
 //   map.nbr       [K,n_out]        output-stationary neighbour table (-1 = absent)
 //   map.pair_in / pair_out [M]     the same pairs compacted per offset, ascending out-row
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -102,8 +103,26 @@ struct pcmi_coords {
   std::vector<pcmi::MapEntry> maps;
   int32_t* d_flags = nullptr;  // [4] device status words (dup count, range errors, ...)
   int64_t* d_total = nullptr;  // device scalar for scan totals
-  int64_t* h_pinned = nullptr; // pinned host staging for small read-backs
+  int64_t* h_pinned = nullptr; // pinned host staging for small read-backs (4096 bytes)
+  // pcmi_coords_plan_unet with PCMI_PLAN_DEFER=1: the maps' per-offset pair counts are copied to their own slots of the
+  // pinned buffer without waiting, and ONE stream synchronisation at the end of the plan fills offs_host / M of all of
+  // them (nothing between two maps needs those numbers on the host: the pair lists are sized by their bound)
+  bool defer_maps = false;
+  std::vector<std::pair<int, int>> pending;  // (index in `maps`, slot)
 };
+constexpr int kMapSlot0 = 64, kMapSlotLen = PCMI_MAX_KERNEL_VOLUME + 1, kMapSlots = (512 - kMapSlot0) / kMapSlotLen;
+
+static int resolve_pending_maps(pcmi_coords* h, hipStream_t st) {
+  if (h->pending.empty()) return PCMI_OK;
+  PCMI_HIP_CHECK(hipStreamSynchronize(st));
+  for (const auto& pr : h->pending) {
+    pcmi_kmap_t& m = h->maps[pr.first].map;
+    memcpy(m.offs_host, h->h_pinned + kMapSlot0 + (size_t)pr.second * kMapSlotLen, sizeof(int64_t) * (m.K + 1));
+    m.M = m.offs_host[m.K];
+  }
+  h->pending.clear();
+  return PCMI_OK;
+}
 
 namespace pcmi {
 
@@ -486,6 +505,8 @@ int pcmi_coords_reset(pcmi_coords_t* h) {
   PCMI_REQUIRE(h, PCMI_ERR_INVALID, "null handle");
   h->levels.clear();
   h->maps.clear();
+  h->pending.clear();
+  h->defer_maps = false;
   h->persistent.reset();
   h->scratch.reset();
   return PCMI_OK;
@@ -675,6 +696,7 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
   const int64_t n_out = Lout.n;
   const int64_t tiles = std::max<int64_t>(ceil_div(n_out, kMapTile), 1);
   const int64_t tot = (int64_t)K * n_out;
+  int defer_slot = -1;  // >= 0: the pair counts are on their way to that pinned slot (resolve_pending_maps)
   // pair lists are sized by their a-priori bound so that the only read-back is the K+1 offsets
   const int64_t pair_bound = stride == 1 ? tot : Lin.n;
   int32_t* nbr = h->persistent.alloc_n<int32_t>(tot);
@@ -710,9 +732,19 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
     kmap_compact_kernel<<<dim3((unsigned)ceil_div(tot, 256)), 256, 0, st>>>(nbr, K, n_out, pos, h->d_total,
                                                                            pair_in, pair_out, offs);
     PCMI_LAUNCH_CHECK();
-    rc = read_back(h, offs, sizeof(int64_t) * (K + 1), st);
-    if (rc) return rc;
-    memcpy(m.offs_host, h->h_pinned, sizeof(int64_t) * (K + 1));
+    if (h->defer_maps) {
+      if ((int)h->pending.size() >= kMapSlots) {
+        rc = resolve_pending_maps(h, st);
+        if (rc) return rc;
+      }
+      defer_slot = (int)h->pending.size();
+      PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kMapSlot0 + (size_t)defer_slot * kMapSlotLen, offs, sizeof(int64_t) * (K + 1),
+                                    hipMemcpyDeviceToHost, st));
+    } else {
+      rc = read_back(h, offs, sizeof(int64_t) * (K + 1), st);
+      if (rc) return rc;
+      memcpy(m.offs_host, h->h_pinned, sizeof(int64_t) * (K + 1));
+    }
   } else {
     PCMI_HIP_CHECK(hipMemsetAsync(offs, 0, sizeof(int64_t) * (K + 1), st));
   }
@@ -751,7 +783,8 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
   m.pair_out = pair_out;
   m.offs = offs;
   h->maps.push_back({in_key, out_key, kernel_size, stride, region, m});
-  *out = m;
+  if (defer_slot >= 0) h->pending.push_back({(int)h->maps.size() - 1, defer_slot});
+  *out = m;  // (deferred: offs_host / M are not filled in yet -- pcmi_coords_plan_unet discards this copy)
   return PCMI_OK;
 }
 
@@ -774,6 +807,19 @@ int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int bl
   PCMI_REQUIRE(n_down >= 0 && n_down <= 8, PCMI_ERR_INVALID, "plan_unet: bad depth");
   pcmi_kmap_t tmp;
   int key = 0;
+  // PCMI_PLAN_DEFER=1 (off by default until it has been through the GPU suite): one synchronisation for the pair counts
+  // of all the maps instead of one per map -- each of them otherwise waits for a free compute unit behind the
+  // compute streams' resident workgroups ("Host side of the iteration")
+  const char* de = getenv("PCMI_PLAN_DEFER");
+  struct Defer {  // also on the error paths: a later pcmi_kmap_get must never find a map without its counts
+    pcmi_coords_t* h;
+    hipStream_t st;
+    ~Defer() {
+      (void)resolve_pending_maps(h, st);
+      h->defer_maps = false;
+    }
+  } defer{h, as_stream(stream)};
+  h->defer_maps = de && de[0] == '1';
   int rc = pcmi_kmap_get(h, 0, 0, 3, 1, first_region, &tmp, stream);
   if (rc) return rc;
   for (int l = 0; l <= n_down; ++l) {
@@ -788,7 +834,8 @@ int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int bl
     if (rc) return rc;
     key = ck;
   }
-  return PCMI_OK;
+  h->defer_maps = false;
+  return resolve_pending_maps(h, as_stream(stream));
 }
 
 }  // extern "C"
