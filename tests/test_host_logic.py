@@ -107,6 +107,39 @@ def test_pair_selection_matches_oracle():
   assert (_hash(pp.astype(np.int64), 1000) == lr.hash_pairs(pp[:, 0], pp[:, 1], 1000)).all()
 
 
+def test_pair_selection_consumes_the_reference_rng_streams_and_accepts_unsorted_pairs():
+  """The un-injected path of select_pairs: torch.rand(n) is value- and generator-identical to the reference's
+  torch.distributions.Uniform(0, 1).sample([n]) (pc/lib/ddp_trainer.py:408), the sub-sample is the reference's
+  np.random.choice(n, npos, replace=False) (:412) -- so under the same seeds the selection equals the oracle fed with the
+  reference's draws; an unsorted pair list is sorted first (stable), an empty one selects nothing."""
+  from oracle import loss_ref as lr
+  from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
+  rng = np.random.RandomState(1)
+  q = np.sort(rng.randint(0, 5000, 60000))
+  pp = np.stack([q, rng.randint(0, 9000, 60000)], 1).astype(np.int32)
+  nq = len(np.unique(q))
+  torch.manual_seed(7)
+  np.random.seed(11)
+  a = PointNCELossTrainer.select_pairs(torch.from_numpy(pp), 4096)
+  torch.manual_seed(7)
+  np.random.seed(11)
+  u = torch.distributions.Uniform(0, 1).sample([nq])
+  si = np.random.choice(nq, 4096, replace=False)
+  b = lr.nce_select_pairs(pp, u, si)
+  assert torch.equal(a[0], torch.as_tensor(b[0]).long()) and torch.equal(a[1], torch.as_tensor(b[1]).long())
+  assert a[0].dtype == torch.int64 and a[0].shape == (4096,)
+  # unsorted input == the same pairs stably sorted by query row
+  shuffled = pp[rng.permutation(len(pp))]
+  u2 = torch.rand(nq)
+  x = PointNCELossTrainer.select_pairs(torch.from_numpy(shuffled), 10 ** 9, dict(uniform=u2))
+  y = PointNCELossTrainer.select_pairs(shuffled[np.argsort(shuffled[:, 0], kind="stable")], 10 ** 9, dict(uniform=u2))
+  assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and x[0].shape == (nq,)
+  e = PointNCELossTrainer.select_pairs(torch.zeros((0, 2), dtype=torch.int32), 4096)
+  assert e[0].numel() == 0 and e[1].numel() == 0
+  one = PointNCELossTrainer.select_pairs(torch.tensor([[5, 7]], dtype=torch.int32), 4096, dict(uniform=torch.tensor([0.9])))
+  assert one[0].tolist() == [5] and one[1].tolist() == [7]
+
+
 def test_model_lowers_to_a_valid_network_program(built_lib):
   """Tracing + pcmi_net_create need no GPU: the static program of Res16UNet34C is well formed
   (every gradient contribution is either a first write or a full accumulate, slices fit)."""
