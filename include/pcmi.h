@@ -295,7 +295,9 @@ int pcmi_match_radius(const double* src, int64_t n0, const double* rigid3x4_host
 /* Softmax cross-entropy over the rows of logits [n, c] with an ignore label -- the loss of the downstream semantic
  * segmentation fine-tuning that reuses this backbone with out_channels = number of classes
  * (downstream/semseg/lib/train.py:64,124: nn.CrossEntropyLoss(ignore_index=config.ignore_label)).
- * out2[0] = mean loss over the counted rows, out2[1] = their number (device).  _bwd: dlogits = gloss[0] * dloss/dlogits. */
+ * out2[0] = mean loss over the counted rows, out2[1] = their number (device).  _bwd: dlogits = gloss[0] * dloss/dlogits.
+ * A label that is neither in [0, c) nor the ignore label (torch raises for it) makes the loss and its row of dlogits
+ * NaN -- a mis-mapped dataset label fails loudly instead of dropping points from the loss. */
 size_t pcmi_softmax_ce_workspace_bytes(int64_t n);
 int pcmi_softmax_ce_fwd(const float* logits, int64_t ld, int64_t n, int c, const int32_t* labels,
                         int ignore_label, float* out2, void* ws, size_t ws_bytes, pcmi_stream_t stream);
@@ -305,6 +307,13 @@ int pcmi_softmax_ce_bwd(const float* logits, int64_t ld, int64_t n, int c, const
 
 int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum,
                   float weight_decay, float grad_scale, pcmi_stream_t stream);
+/* The same with torch's dampening (the downstream fine-tuning's optimiser: SGD(lr, sgd_momentum, dampening =
+ * sgd_dampening 0.1, weight_decay), downstream/semseg/lib/solvers.py:52-60, config/default.yaml:16-19):
+ *   v = mu*v + (1 - dampening)*g, except on the optimiser's first step (first_step != 0, v zero-filled), where torch
+ *   initialises the buffer with g itself. */
+int pcmi_sgd_step_dampened(float* w, const float* g, float* v, int64_t n, float lr, float momentum,
+                           float dampening, float weight_decay, float grad_scale, int first_step,
+                           pcmi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Network executor -- the reference drives the 63 convs / 62 BNs of Res16UNet34C from Python

@@ -492,7 +492,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ x
   float v[2] = {0.f, 0.f};
   if (r < n) {
     const int32_t lb = label[r];
-    if (lb != ignore && lb >= 0 && lb < c) {
+    if (lb != ignore && (lb < 0 || lb >= c)) {
+      // torch.nn.CrossEntropyLoss raises for a label that is neither a class nor the ignore index; a kernel cannot
+      // raise, so the loss (and every gradient behind it) becomes NaN instead of the row being dropped silently
+      v[0] = __builtin_nanf("");
+      v[1] = 1.f;
+    } else if (lb != ignore) {
       const float* xr = x + r * ld;
       float m = -INFINITY;
       for (int j = 0; j < c; ++j) m = fmaxf(m, xr[j]);
@@ -533,7 +538,11 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x
   if (r >= n) return;
   const int32_t lb = label[r];
   float* dr = dx + r * dx_ld;
-  if (lb == ignore || lb < 0 || lb >= c || stats[1] <= 0.f) {
+  if (lb != ignore && (lb < 0 || lb >= c)) {  // see ce_fwd_kernel: a mis-mapped label poisons, it is not dropped
+    for (int j = 0; j < c; ++j) dr[j] = __builtin_nanf("");
+    return;
+  }
+  if (lb == ignore || stats[1] <= 0.f) {
     for (int j = 0; j < c; ++j) dr[j] = 0.f;
     return;
   }
@@ -548,16 +557,17 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ x
 
 // ---- SGD ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
-                                                  int64_t n, float lr, float mu, float wd, float gscale) {
+                                                  int64_t n, float lr, float mu, float wd, float gscale, float gcoef) {
+  // gcoef = 1 - dampening (1 on the first step: torch initialises the buffer with the gradient itself)
   const int64_t n4 = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 wv = reinterpret_cast<float4*>(w)[i];
     const float4 gv = reinterpret_cast<const float4*>(g)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
-    vv.x = mu * vv.x + (gscale * gv.x + wd * wv.x);
-    vv.y = mu * vv.y + (gscale * gv.y + wd * wv.y);
-    vv.z = mu * vv.z + (gscale * gv.z + wd * wv.z);
-    vv.w = mu * vv.w + (gscale * gv.w + wd * wv.w);
+    vv.x = mu * vv.x + gcoef * (gscale * gv.x + wd * wv.x);
+    vv.y = mu * vv.y + gcoef * (gscale * gv.y + wd * wv.y);
+    vv.z = mu * vv.z + gcoef * (gscale * gv.z + wd * wv.z);
+    vv.w = mu * vv.w + gcoef * (gscale * gv.w + wd * wv.w);
     wv.x -= lr * vv.x;
     wv.y -= lr * vv.y;
     wv.z -= lr * vv.z;
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
   if (blockIdx.x == 0) {
     const int64_t i = n4 * 4 + threadIdx.x;
     if (i < n) {
-      const float vv = mu * v[i] + (gscale * g[i] + wd * w[i]);
+      const float vv = mu * v[i] + gcoef * (gscale * g[i] + wd * w[i]);
       v[i] = vv;
       w[i] -= lr * vv;
     }
@@ -781,15 +791,22 @@ int pcmi_softmax_ce_bwd(const float* logits, int64_t ld, int64_t n, int c, const
   return PCMI_OK;
 }
 
-int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
-                  float grad_scale, pcmi_stream_t stream) {
+int pcmi_sgd_step_dampened(float* w, const float* g, float* v, int64_t n, float lr, float momentum, float dampening,
+                           float weight_decay, float grad_scale, int first_step, pcmi_stream_t stream) {
   PCMI_REQUIRE(w && g && v && n >= 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)v % 16 == 0,
                PCMI_ERR_INVALID, "sgd_step: buffers must be 16-byte aligned");
+  PCMI_REQUIRE(dampening >= 0.f && dampening <= 1.f, PCMI_ERR_INVALID, "sgd_step: dampening %g outside [0, 1]", (double)dampening);
   if (n == 0) return PCMI_OK;
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(n / 4, 256), 256 * 8));
-  sgd_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, g, v, n, lr, momentum, weight_decay, grad_scale);
+  sgd_kernel<<<grid, 256, 0, as_stream(stream)>>>(w, g, v, n, lr, momentum, weight_decay, grad_scale,
+                                                  first_step ? 1.f : 1.f - dampening);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
+}
+
+int pcmi_sgd_step(float* w, const float* g, float* v, int64_t n, float lr, float momentum, float weight_decay,
+                  float grad_scale, pcmi_stream_t stream) {
+  return pcmi_sgd_step_dampened(w, g, v, n, lr, momentum, 0.f, weight_decay, grad_scale, 1, stream);
 }
 
 }  // extern "C"

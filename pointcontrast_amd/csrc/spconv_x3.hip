@@ -53,7 +53,12 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-// 8 floats (element e = x0[e] for e < 4, x1[e - 4] otherwise) -> three vectors of 8 bf16 with x = h + m + l
+// 8 floats (element e = x0[e] for e < 4, x1[e - 4] otherwise) -> three vectors of 8 bf16 with x = h + m + l.
+// Special values: an element that rounds to +-inf in bf16 (|x| >= 3.39e38, or inf itself) has h = inf and residuals
+// x - inf = -inf / NaN, so its products come out NaN where the fp32 kernel yields +-inf.  Zeroing the residuals of such
+// an element does not restore inf either: inf * b_h + inf * b_m + inf * b_l mixes signs (the residual terms of a weight
+// have arbitrary sign) and is NaN again.  An overflowed activation therefore shows up as NaN in its whole output tile
+// (documented in INTEGRATION.md; PCMI_CONV16_X3=0 selects the fp32-MFMA kernel to localise a divergence).
 __device__ __forceinline__ void split3(const v4f& x0, const v4f& x1, u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {

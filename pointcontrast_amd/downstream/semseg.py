@@ -61,8 +61,8 @@ def per_class_iu(hist):
 class SegmentationTrainer:
   """One process per GPU; `train_iter(coords, feats, target)` = forward, cross-entropy, backward, SGD + PolyLR step."""
 
-  def __init__(self, num_labels, in_channels=3, model="Res16UNet34C", lr=0.1, momentum=0.9, weight_decay=1e-4,
-               max_iter=60000, poly_power=0.9, ignore_label=255, bn_momentum=0.02, pretrained=None,
+  def __init__(self, num_labels, in_channels=3, model="Res16UNet34C", lr=0.1, momentum=0.9, dampening=0.1,
+               weight_decay=1e-4, max_iter=60000, poly_power=0.9, ignore_label=255, bn_momentum=0.02, pretrained=None,
                kernel_order="hybrid", device=None):
     assert torch.cuda.is_available(), "the fine-tuning step runs on a gfx950 GPU (no CPU path)"
     self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -76,7 +76,8 @@ class SegmentationTrainer:
       self.model.load_state_dict(own)
     self.flat = FlatParameters(self.model.parameters())
     self.engine = NativeEngine(self.model, self.flat, in_channels=in_channels, n_passes=1)
-    self.optimizer = FlatSGD(self.flat, lr=lr, momentum=momentum, weight_decay=weight_decay)
+    # downstream/semseg/lib/solvers.py:52-60: SGD(lr, momentum=sgd_momentum 0.9, dampening=sgd_dampening 0.1, weight_decay)
+    self.optimizer = FlatSGD(self.flat, lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=dampening)
     self.scheduler = PolyLR(self.optimizer, max_iter=max_iter, power=poly_power)
     self.ignore_label, self.num_labels, self.curr_iter = ignore_label, num_labels, 0
 
@@ -87,6 +88,11 @@ class SegmentationTrainer:
   def train_iter(self, coords, feats, target):
     self.model.train()
     self.optimizer.zero_grad()
+    if torch.is_tensor(target) and not target.is_cuda and target.numel():  # free on the host; as torch's CrossEntropyLoss
+      bad = (target != self.ignore_label) & ((target < 0) | (target >= self.num_labels))
+      if bool(bad.any()):
+        raise IndexError("Target %d is out of bounds (classes 0..%d, ignore label %d)" %
+                         (int(target[bad][0]), self.num_labels - 1, self.ignore_label))
     logits = self.forward(coords, feats).requires_grad_(True)
     tgt = target.to(self.device)
     loss = PF.SoftmaxCrossEntropyFunction.apply(logits, tgt, self.ignore_label)

@@ -343,8 +343,9 @@ class SoftmaxCrossEntropyFunction(Function):
     return dx, None, None
 
 
-def sgd_step(w, g, v, lr, momentum, weight_decay, grad_scale=1.0):
-  """torch.optim.SGD.step on flat buffers (pc/lib/ddp_trainer.py:107-111,319,435)."""
+def sgd_step(w, g, v, lr, momentum, weight_decay, grad_scale=1.0, dampening=0.0, first_step=True):
+  """torch.optim.SGD.step on flat buffers (pc/lib/ddp_trainer.py:107-111,319,435; with dampening:
+  downstream/semseg/lib/solvers.py:52-60).  first_step: torch fills a fresh momentum buffer with the gradient itself."""
   require_cuda(w, "sgd step")
-  check(lib.pcmi_sgd_step(ptr(w), ptr(g), ptr(v), w.numel(), float(lr), float(momentum), float(weight_decay),
-                          float(grad_scale), cur_stream(w.device)))
+  check(lib.pcmi_sgd_step_dampened(ptr(w), ptr(g), ptr(v), w.numel(), float(lr), float(momentum), float(dampening),
+                                   float(weight_decay), float(grad_scale), int(bool(first_step)), cur_stream(w.device)))

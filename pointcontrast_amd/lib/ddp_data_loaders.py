@@ -160,6 +160,11 @@ def make_data_loader(config, batch_size, num_threads=0):
   dset = Dataset(phase="train", transform=FeatureJitter(), random_scale=config.trainer.use_random_scale,
                  random_rotation=config.trainer.use_random_rotation, config=config)
   batch_size = batch_size // config.misc.num_gpus  # per-GPU batch, pc/lib/ddp_data_loaders.py:292
+  if getattr(dset, "device_geometry", False) and num_threads > 0:
+    # __getitem__ then launches HIP kernels (lib/device_loader.py): a forked DataLoader worker cannot use the parent's
+    # HIP context ("Cannot re-initialize CUDA in forked subprocess") -- the items are produced on the training process
+    raise ValueError("data.device_geometry=True needs misc.train_num_thread=0 (got %d): the dataset runs libpcmi "
+                     "kernels in __getitem__, which forked DataLoader workers cannot do" % num_threads)
   # The training loop calls iter() once and next() until opt.max_iter (pc/lib/ddp_trainer.py:128-140), so the loader
   # must never run dry: infinite samplers on ANY number of GPUs (the reference's single-GPU DataLoader is finite and
   # raises StopIteration after one epoch).

@@ -146,3 +146,112 @@ def test_reducer_through_engine_bucket_mapping_world2_gloo():
     assert p.exitcode == 0
   assert all(ok for _, ok, _, _ in out), out
   assert all(desc for _, _, desc, _ in out), "buckets must become final from the END of the flat buffer: %r" % (out,)
+
+
+def _trainer_worker(rank, world, port, q):
+  """The trainer's OWN control flow for the N > 1 step (lib/ddp_trainer.py::_backward_and_step: loss.backward ->
+  engine.backward(reducer) -> reducer.finish -> scaled_all_reduce_dict -> optimizer.step, and zero_grad on the next
+  iteration) on gloo, with CPU stand-ins for exactly the two things that need the GPU: the network executor (a torch
+  module whose backward writes the flat gradient buffer in the executor's order and reports buckets through the real
+  NativeEngine._ready_args callback) and the fused SGD kernel (the same formula in torch).  pc/lib/ddp_trainer.py:96-102
+  (DDP wrap), :428-435 (backward, step)."""
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  import types
+  from pointcontrast_amd.engine import NativeEngine
+  from pointcontrast_amd.lib import distributed as du
+  from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
+  from pointcontrast_amd.lib.solver import FlatSGD
+  du.init_process_group(rank, world, backend="gloo")
+
+  def make_model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Linear(5, 24), torch.nn.Tanh(), torch.nn.Linear(24, 24), torch.nn.Tanh(),
+                               torch.nn.Linear(24, 8))
+
+  class CpuSGD(FlatSGD):  # csrc/loss.hip::sgd_kernel restated
+    def step(self, closure=None):
+      g = self.param_groups[0]
+      with torch.no_grad():
+        grad = self.grad_scale * self.flat.g + g["weight_decay"] * self.flat.w
+        self.flat.v.mul_(g["momentum"]).add_(grad)
+        self.flat.w.sub_(g["lr"] * self.flat.v)
+
+  class CpuEngine:  # stands in for NativeEngine: parameter gradients appear from the END of the flat buffer
+    def __init__(self, model, flat):
+      self.model, self.flat, self.fired = model, flat, []
+
+    def forward(self, x):
+      self._out = self.model(x)
+      return self._out.detach().requires_grad_(True)
+
+    def backward(self, pass_id, d_out, reducer=None):
+      cb, lo_arr, nb = NativeEngine._ready_args(reducer)
+      lo = [lo_arr[i] for i in range(nb)]
+      grads = torch.autograd.grad(self._out, self.flat.params, d_out)
+      first_param_of = {}  # bucket -> lowest parameter index inside it: the bucket is final after that parameter
+      for i, off in enumerate(self.flat.offsets):
+        b = max(qq for qq in range(nb) if off >= lo[qq])
+        first_param_of.setdefault(b, i)
+      for i in range(len(self.flat.params) - 1, -1, -1):
+        self.flat.view(self.flat.g, i).add_(grads[i])
+        for b, first in first_param_of.items():
+          if first == i:
+            self.fired.append(b)
+            cb(None, b)
+
+  def loss_fn(F):  # decomposes over the samples: the mean over a 2x batch = the mean of the two ranks' means
+    return (F.pow(2).sum(1) - F[:, 0]).mean()
+
+  model = make_model()
+  flat = du.FlatParameters(model.parameters())
+  red = du.GradReducer(flat, bucket_mb=0.0005)
+  assert red.active and len(red.buckets) >= 3
+  tr = PointNCELossTrainer.__new__(PointNCELossTrainer)
+  tr.config = types.SimpleNamespace(misc={})
+  tr.engine, tr.reducer, tr.world_size = CpuEngine(model, flat), red, world
+  tr.optimizer = CpuSGD(flat, lr=0.1, momentum=0.8, weight_decay=1e-4, grad_scale=red.grad_scale)
+  torch.manual_seed(11)
+  data = [torch.randn(2 * 6, 5) for _ in range(2)]
+  losses = []
+  for it in range(2):  # two iterations: bucket bookkeeping, zero_grad and momentum carry over
+    tr.optimizer.zero_grad()
+    F = tr.engine.forward(data[it][rank * 6:(rank + 1) * 6])
+    tr._feats = (F,)
+    loss = loss_fn(F)
+    res = tr._backward_and_step(loss, {"loss": loss.detach()})
+    losses.append(float(res["loss"]))
+  assert tr.engine.fired[:len(red.buckets)] == sorted(tr.engine.fired[:len(red.buckets)], reverse=True)
+  assert red.n_launched_total == 2 * len(red.buckets)
+  # single process, 2x batch, torch's own SGD
+  ref = make_model()
+  opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.8, weight_decay=1e-4)
+  ref_losses = []
+  for it in range(2):
+    opt.zero_grad()
+    parts = [loss_fn(ref(data[it][r * 6:(r + 1) * 6])) for r in range(world)]
+    total = sum(parts) / world
+    total.backward()
+    opt.step()
+    ref_losses.append(float(total))
+  err = max(float((p - r).abs().max()) for p, r in zip(model.parameters(), ref.parameters()))
+  q.put((rank, err, losses, ref_losses, flat.w.clone().numpy()))
+  du.destroy_process_group()
+
+
+def test_trainer_step_control_flow_world2_gloo():
+  """Post-step weights are identical on both ranks and equal the single-process step on the 2x batch; the logged loss is
+  the mean over ranks."""
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  out = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert (out[0][4] == out[1][4]).all(), "ranks ended the step with different weights"
+  for rank, err, losses, ref_losses, _ in out:
+    assert err <= 1e-6, (rank, err)
+    assert all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(losses, ref_losses)), (losses, ref_losses)

@@ -29,6 +29,22 @@ def assert_close(got, ref, tol=1e-4, what=""):
   assert e <= tol, "%s: rel err %.3e > %.1e (shape %s)" % (what, e, tol, tuple(ref.shape))
 
 
+def row_err(got, ref):
+  """Worst ROW of a feature matrix: max_r |got_r - ref_r|_2 / |ref_r|_2.  The max-norm criterion above divides by the
+  largest entry of the whole matrix, so a row of small features could be 10 % off and pass; the losses consume
+  L2-normalised rows, so every row is held to the tolerance on its own scale."""
+  got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+  num = (got - ref).norm(dim=1)
+  den = ref.norm(dim=1).clamp_min(1e-30)
+  return float((num / den).max())
+
+
+def assert_rows_close(got, ref, tol=1e-4, what=""):
+  assert_close(got, ref, tol, what)
+  e = row_err(got, ref)
+  assert e <= tol, "%s: worst row rel err %.3e > %.1e (shape %s)" % (what, e, tol, tuple(ref.shape))
+
+
 @pytest.fixture(scope="module")
 def ME():
   import pointcontrast_amd.minkowski as me
@@ -460,18 +476,21 @@ def test_hardest_loss_parity(N0, N1, P, S):
   assert_close(F1d.grad, F1r.grad, 1e-4, "hardest dF1")
 
 
-def test_sgd_step_matches_torch():
+@pytest.mark.parametrize("dampening", [0.0, 0.1])
+def test_sgd_step_matches_torch(dampening):
+  """dampening 0 = the pre-training optimiser (pc/lib/ddp_trainer.py:107-111), 0.1 = the downstream fine-tuning's
+  (downstream/semseg/lib/solvers.py:52-60): torch applies it from the SECOND step on."""
   from pointcontrast_amd import functional as PF
   torch.manual_seed(0)
   w = torch.randn(100003)
   p = torch.nn.Parameter(w.clone())
-  opt = torch.optim.SGD([p], lr=0.1, momentum=0.8, weight_decay=1e-4)
+  opt = torch.optim.SGD([p], lr=0.1, momentum=0.8, dampening=dampening, weight_decay=1e-4)
   wd, vd = w.to(DEV), torch.zeros(100003, device=DEV)
   for it in range(3):
     g = torch.randn(100003)
     p.grad = g.clone()
     opt.step()
-    PF.sgd_step(wd, (2.0 * g).to(DEV), vd, 0.1, 0.8, 1e-4, grad_scale=0.5)
+    PF.sgd_step(wd, (2.0 * g).to(DEV), vd, 0.1, 0.8, 1e-4, grad_scale=0.5, dampening=dampening, first_step=(it == 0))
   assert_close(wd, p.data, 1e-6, "sgd weights")
   assert_close(vd, opt.state[p]["momentum_buffer"], 1e-6, "sgd momentum")
 
@@ -525,7 +544,7 @@ class _device_relu_masks:
     return False
 
 
-def _network_case(ME, name, crop, batch, seed):
+def _network_case(ME, name, crop, batch, seed, npos=512, voxel_size=0.025):
   """Features / loss / parameter gradients of the device model vs the oracle on one synthetic batch.
   Returns the per-tensor gradient report [(dev_err, ref32_err, name, |g|max)], worst first."""
   import copy
@@ -539,10 +558,10 @@ def _network_case(ME, name, crop, batch, seed):
   ref.train()
   dev.train()
   state0 = copy.deepcopy(ref.state_dict())
-  b = synthetic.make_batch(seed=seed, batch_size=batch, crop=crop)
+  b = synthetic.make_batch(seed=seed, batch_size=batch, crop=crop, voxel_size=voxel_size)
   Fin = {s: torch.from_numpy(b["sinput%s_F" % s]) for s in "01"}
   nq = len(np.unique(b["correspondences"][:, 0]))
-  npos = min(512, nq)
+  npos = min(npos, nq)
   qi, ki = PointNCELossTrainer.select_pairs(torch.from_numpy(b["correspondences"]), npos,
                                             dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(1)),
                                                  sampled_inds=np.random.RandomState(1).choice(nq, npos, replace=False)))
@@ -559,7 +578,7 @@ def _network_case(ME, name, crop, batch, seed):
   fr = [ref(sr.SparseTensorRef(Fin[s], coords=b["sinput%s_C" % s])).F for s in "01"]
   fd = dev_forward()
   for i in range(2):
-    assert_close(fd[i], fr[i], 1e-4, "%s features cloud %d" % (name, i))
+    assert_rows_close(fd[i], fr[i], 1e-4, "%s features cloud %d" % (name, i))
   lref, ld = lr.nce_loss(fr[0], fr[1], qi, ki, 0.4), dev_loss(fd)
   assert abs(float(ld) - float(lref)) <= 1e-4 * abs(float(lref)), (float(ld), float(lref))
   # BN running statistics were updated twice (two forwards), identically
@@ -583,7 +602,7 @@ def _network_case(ME, name, crop, batch, seed):
     fdm = dev_forward()
   dev_loss(fdm).backward()
   for i in range(2):
-    assert_close(fdm[i], f64[i], 1e-4, "%s features (masks imposed) cloud %d" % (name, i))
+    assert_rows_close(fdm[i], f64[i], 1e-4, "%s features (masks imposed) cloud %d" % (name, i))
   print("%s seed %d: %d of %d ReLU outputs sat on the other side of the kink (%.2e)" %
         (name, seed, inj.flips, inj.total, inj.flips / max(inj.total, 1)))
   assert inj.flips <= 1e-4 * inj.total
@@ -604,14 +623,15 @@ def _network_case(ME, name, crop, batch, seed):
                                                   ("Res16UNet34C", 0.8, 2, 6)])
 def test_network_features_loss_and_grads(ME, name, crop, batch, seed):
   """Whole network against the oracle, EVERY seed must pass.  Features and loss: 1e-4.  Parameter gradients: every
-  tensor within 10x the fp32 oracle's own error against the fp64 oracle (floor 5e-4 of the tensor's largest entry).
+  tensor within 10x the fp32 oracle's own error against the fp64 oracle (floor 5e-5 of the tensor's largest entry;
+  observed on MI355X: device 4-9e-6, fp32 oracle 2-5e-6).
   The comparison is deterministic because all three runs share the fp64 oracle's ReLU masks (an activation within
   fp32 round-off of zero otherwise gets opposite masks and moves whole gradient tensors by percents -- see
   oracle.model_ref.relu_masks); the count of such activations is printed and bounded."""
   report = _network_case(ME, name, crop, batch, seed)
   msg = "; ".join("%s dev=%.2e ref32=%.2e" % (n_, d_, r_) for d_, r_, n_, g_ in report[:4])
   print("worst gradient tensors:", msg)
-  bad = [(n_, d_, r_) for d_, r_, n_, _ in report if d_ > max(10 * r_, 5e-4)]
+  bad = [(n_, d_, r_) for d_, r_, n_, _ in report if d_ > max(10 * r_, 5e-5)]
   assert not bad, "gradient tensors off: %s | worst: %s" % (bad[:5], msg)
 
 
@@ -637,7 +657,7 @@ def test_full_config_forward_and_loss_match_oracle(ME):
   with torch.no_grad():
     fr = [ref(sr.SparseTensorRef(torch.from_numpy(b["sinput%s_F" % s]), coords=b["sinput%s_C" % s])).F for s in "01"]
   for i in range(2):
-    assert_close(fd[i], fr[i], 1e-4, "full-size features cloud %d" % i)
+    assert_rows_close(fd[i], fr[i], 1e-4, "full-size features cloud %d" % i)
   nq = len(np.unique(b["correspondences"][:, 0]))
   qi, ki = PointNCELossTrainer.select_pairs(torch.from_numpy(b["correspondences"]), 4096,
                                             dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(2)),
@@ -687,7 +707,7 @@ def test_engine_matches_autograd_path(ME, name, crop, batch):
   names = {id(p): n for n, p in dev.named_parameters()}
   msg = "; ".join("%s %.2e" % (names[id(flat.params[i])], e) for e, i in per[:5])
   print("engine vs autograd worst gradient tensors:", msg)
-  assert per[0][0] <= 2e-3, msg
+  assert per[0][0] <= 2e-4, msg
   for k, v in dev.state_dict().items():
     if "running" in k:
       assert_close(v, rs_after[k], 1e-5, "engine " + k)

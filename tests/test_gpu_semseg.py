@@ -43,6 +43,12 @@ def test_softmax_cross_entropy_with_ignore_label(n, c):
   assert_close(xd.grad, xr.grad, 1e-5, "dlogits")
   all_ignored = PF.SoftmaxCrossEntropyFunction.apply(x.to(DEV), torch.full((n,), 255), 255)
   assert float(all_ignored) == 0.0
+  # a label that is neither a class nor the ignore label: torch raises, the kernel poisons the loss (never drops the row)
+  bad = lb.clone()
+  bad[n // 2] = c + 3
+  with pytest.raises((IndexError, RuntimeError)):
+    torch.nn.functional.cross_entropy(x, bad, ignore_index=255)
+  assert np.isnan(float(PF.SoftmaxCrossEntropyFunction.apply(x.to(DEV), bad.to(DEV), 255)))
 
 
 @pytest.mark.parametrize("engine", ["autograd", "native"])
@@ -97,7 +103,8 @@ def test_segmentation_head_forward_loss_and_head_gradients(ME, engine):
 
 def test_segmentation_trainer_steps_match_oracle(tmp_path):
   """pointcontrast_amd.downstream.semseg.SegmentationTrainer: pre-trained backbone loaded by name and shape (the
-  32-wide contrastive head is skipped), then two fine-tuning iterations -- forward, CE(ignore 255), backward, SGD(0.9)
+  32-wide contrastive head is skipped), then two fine-tuning iterations -- forward, CE(ignore 255), backward,
+  SGD(momentum 0.9, dampening 0.1: the reference's defaults)
   + PolyLR -- against the oracle model + torch CrossEntropyLoss / SGD / the reference's PolyLR formula.  Every step
   starts from the device's state (see test_trainer_iteration_matches_oracle)."""
   from oracle import model_ref as mr, sparse_ref as sr
@@ -114,7 +121,8 @@ def test_segmentation_trainer_steps_match_oracle(tmp_path):
   assert sd["final.kernel"].shape == (256, 20)
   ref = mr.MODELS["Res16UNet14"](3, 20, bn_momentum=0.02, normalize_feature=False)
   ref.train()
-  opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, dampening=0, weight_decay=1e-4)
+  # the reference's fine-tuning optimiser: downstream/semseg/lib/solvers.py:52-60 with config/default.yaml:16-19
+  opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, dampening=0.1, weight_decay=1e-4)
   b = synthetic.make_batch(seed=8, batch_size=2, crop=0.6)
   C, F = torch.from_numpy(b["sinput0_C"]), torch.from_numpy(b["sinput0_F"])
   target = torch.from_numpy(np.random.RandomState(1).randint(0, 20, len(C)))

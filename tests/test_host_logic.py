@@ -297,6 +297,12 @@ def test_scannet_match_pair_dataset_and_infinite_loader(tmp_path):
     assert (np.diff(batch["correspondences"][:, 0].numpy()) >= 0).all()
   with pytest.raises(ValueError, match="does not exist"):
     make_data_loader(get_config(["data.dataset=Nope"]), 4)
+  # device-side geometry launches HIP kernels in __getitem__: forked loader workers are refused, not left to crash
+  cfg_dev = get_config(["data.dataset=ScanNetMatchPairDataset", "data.dataset_root_dir=%s" % tmp_path,
+                        "data.scannet_match_dir=pairs.txt", "trainer.batch_size=2", "data.device_geometry=True"])
+  with pytest.raises(ValueError, match="train_num_thread=0"):
+    make_data_loader(cfg_dev, 2, num_threads=2)
+  make_data_loader(cfg_dev, 2, num_threads=0)
 
 
 def test_checkpoint_prefixes_and_kernel_order_switch(built_lib):
