@@ -707,7 +707,7 @@ def test_engine_matches_autograd_path(ME, name, crop, batch):
   names = {id(p): n for n, p in dev.named_parameters()}
   msg = "; ".join("%s %.2e" % (names[id(flat.params[i])], e) for e, i in per[:5])
   print("engine vs autograd worst gradient tensors:", msg)
-  assert per[0][0] <= 2e-4, msg
+  assert per[0][0] <= 1e-6, msg  # observed on MI355X: 0.0 (bit-identical accumulation order)
   for k, v in dev.state_dict().items():
     if "running" in k:
       assert_close(v, rs_after[k], 1e-5, "engine " + k)
@@ -799,7 +799,9 @@ def test_trainer_iteration_matches_oracle(which):
   print("worst state tensors after the last step:", msg)
   # one SGD step at lr 0.1 (with momentum from the first) from identical state: the update is lr * (fp32 gradient),
   # whose ill-conditioned tensors carry ~1e-3 relative noise; the loss trace above is the tight check
-  assert report[0][0] <= 2e-2, "state after the step: " + msg
+  # (observed on MI355X: 5.5e-7; the margin is for an activation on the other side of a ReLU kink, which this test
+  # -- the trainer's fused path -- cannot impose masks on)
+  assert report[0][0] <= 2e-3, "state after the step: " + msg
 
 
 def test_rccl_reducer_path_single_rank():
