@@ -74,6 +74,12 @@ int pcmi_coords_destroy(pcmi_coords_t* h);
 int pcmi_coords_reset(pcmi_coords_t* h);
 /* Build the hash of n rows -> key 0.  Syncs (returns PCMI_ERR_DUPLICATE / PCMI_ERR_RANGE). */
 int pcmi_coords_insert(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream);
+/* The same without the synchronisation: the insert is only enqueued, and a duplicate / out-of-range row is reported by
+ * the next call on this handle that synchronises `stream` anyway (pcmi_coords_plan_unet, pcmi_coords_stride, a
+ * pcmi_kmap_get miss) or by pcmi_coords_check.  For callers that plan the whole network right behind the insert
+ * (the training step: one host wait per batch instead of one per call). */
+int pcmi_coords_insert_deferred(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream);
+int pcmi_coords_check(pcmi_coords_t* h, pcmi_stream_t stream); /* syncs if a deferred insert is still unchecked */
 /* Two-segment batches (the two point clouds of a contrastive pair processed as ONE sparse tensor: the reference runs
  * its network once per cloud, ddp_trainer.py:404-407, so BatchNorm statistics are per cloud).  The caller inserts the
  * rows of the first cloud before those of the second, with disjoint batch indices, and declares the boundary;
@@ -92,7 +98,12 @@ int pcmi_coords_get(pcmi_coords_t* h, int key, int32_t* out_bxyz, pcmi_stream_t 
 /* Build every level (strides 2,4,..,2^n_down) and the kernel maps a Res16UNet forward
  * uses up front (typically on a side stream while the compute stream is still busy), so
  * the per-layer calls below all hit the cache and never sync.  Pure performance hint.  first_region: region of the 3^3 stem conv (HYPERCUBE),
- * block_region: region of the 3^3 block convs (HYBRID). */
+ * block_region: region of the 3^3 block convs (HYBRID).
+ * ONE host synchronisation per call (round 2: 16): the levels of a fresh handle are built as a chain whose kernels take
+ * their row counts from the device and whose counts come back together; the maps are then enqueued without waiting for
+ * their per-offset pair counts (pcmi_kmap_get hands those out later; no kernel of this library needs them on the
+ * host).  The tables are complete when `stream` reaches the end of the call: a consumer on another stream must be
+ * ordered behind it (pcmi_net_forward does that itself). */
 int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int block_region,
                           pcmi_stream_t stream);
 /* Bytes currently reserved by the handle's arena (for memory accounting). */
@@ -113,7 +124,8 @@ typedef struct pcmi_kmap {
   int32_t stride;          /* 1 or 2 */
   int32_t region;
   int64_t n_in, n_out;
-  int64_t M;               /* total number of pairs */
+  int64_t M;               /* total number of pairs; -1 in a map taken while pcmi_coords_plan_unet's counts were still
+                            * on their way (internal use: pcmi_kmap_get always returns it filled in) */
   const int32_t* nbr;      /* [K, n_out]: in-row for (k, out-row) or -1 */
   const int32_t* pair_in;  /* [M] grouped by k, ascending out-row inside a group */
   const int32_t* pair_out; /* [M] */

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "pcmi_coords_destroy": (C.c_int, [c_vp]),
     "pcmi_coords_reset": (C.c_int, [c_vp]),
     "pcmi_coords_insert": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "pcmi_coords_insert_deferred": (C.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "pcmi_coords_check": (C.c_int, [c_vp, c_vp]),
     "pcmi_coords_stride": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(c_i64), c_vp]),
     "pcmi_coords_key_at_stride": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_int)]),
     "pcmi_coords_size": (C.c_int, [c_vp, C.c_int, C.POINTER(c_i64), C.POINTER(C.c_int)]),

@@ -103,24 +103,46 @@ struct pcmi_coords {
   std::vector<pcmi::MapEntry> maps;
   int32_t* d_flags = nullptr;  // [4] device status words (dup count, range errors, ...)
   int64_t* d_total = nullptr;  // device scalar for scan totals
+  int64_t* d_counts = nullptr; // [kMaxLevels] rows of every level, [kMaxLevels] first-segment rows (plan_unet's level chain)
   int64_t* h_pinned = nullptr; // pinned host staging for small read-backs (4096 bytes)
-  // pcmi_coords_plan_unet with PCMI_PLAN_DEFER=1: the maps' per-offset pair counts are copied to their own slots of the
-  // pinned buffer without waiting, and ONE stream synchronisation at the end of the plan fills offs_host / M of all of
-  // them (nothing between two maps needs those numbers on the host: the pair lists are sized by their bound)
+  // pcmi_coords_plan_unet builds its maps WITHOUT waiting for their per-offset pair counts: the counts are copied to the
+  // map's own slot of the pinned buffer behind the build, `ev_counts` is recorded behind the last copy, and the host-side
+  // fields (offs_host, M) of those maps are filled in when somebody asks for them (pcmi_kmap_get / pcmi_kmap_export) --
+  // nothing on the training path does: the kernels read the device-side offsets and size their launches by bounds.
   bool defer_maps = false;
   std::vector<std::pair<int, int>> pending;  // (index in `maps`, slot)
+  hipEvent_t ev_counts = nullptr;
+  // recorded on the planning stream at the end of pcmi_coords_plan_unet: a consumer on another stream
+  // (pcmi_net_forward) waits for it before it reads the tables
+  hipEvent_t ev_plan = nullptr;
+  bool plan_recorded = false;
+  bool insert_unchecked = false;  // pcmi_coords_insert_deferred: the status words have not been read yet
 };
+constexpr int kMaxLevels = 16;
+constexpr int kStatusSlot = 2;  // h_pinned[2]: the two int32 status words of the insert (duplicates, out-of-range rows)
+constexpr int kLevelSlot0 = 8;  // h_pinned[8 .. 8 + 2 * kMaxLevels): level sizes and segment boundaries of the level chain
 constexpr int kMapSlot0 = 64, kMapSlotLen = PCMI_MAX_KERNEL_VOLUME + 1, kMapSlots = (512 - kMapSlot0) / kMapSlotLen;
 
-static int resolve_pending_maps(pcmi_coords* h, hipStream_t st) {
+static int resolve_pending_maps(pcmi_coords* h) {
   if (h->pending.empty()) return PCMI_OK;
-  PCMI_HIP_CHECK(hipStreamSynchronize(st));
+  PCMI_HIP_CHECK(hipEventSynchronize(h->ev_counts));
   for (const auto& pr : h->pending) {
     pcmi_kmap_t& m = h->maps[pr.first].map;
     memcpy(m.offs_host, h->h_pinned + kMapSlot0 + (size_t)pr.second * kMapSlotLen, sizeof(int64_t) * (m.K + 1));
     m.M = m.offs_host[m.K];
   }
   h->pending.clear();
+  return PCMI_OK;
+}
+
+// the duplicate / range status of the insert, once a synchronisation of its stream has made the pinned copy current
+// (every synchronising call of this file ends with it: a deferred insert reports its error there)
+static int check_insert_status(pcmi_coords* h) {
+  if (!h->insert_unchecked) return PCMI_OK;
+  h->insert_unchecked = false;
+  const int32_t* f = (const int32_t*)(h->h_pinned + kStatusSlot);
+  PCMI_REQUIRE(f[1] == 0, PCMI_ERR_RANGE, "coords_insert: %d rows outside the packable range", f[1]);
+  PCMI_REQUIRE(f[0] == 0, PCMI_ERR_DUPLICATE, "coords_insert: %d duplicate coordinates", f[0]);
   return PCMI_OK;
 }
 
@@ -274,10 +296,13 @@ __global__ void insert_kernel(const int32_t* __restrict__ coords, int64_t n, uin
 }
 
 // strided level, pass 1: insert the quantised key, remember the slot
-__global__ void stride_insert_kernel(const int32_t* __restrict__ coords, int64_t n, int ts2,
+// (the strided-level kernels take their row count from the device when n_dev != nullptr: pcmi_coords_plan_unet builds
+//  the whole level chain without reading a count back; `n` is then the launch bound)
+__global__ void stride_insert_kernel(const int32_t* __restrict__ coords, int64_t n, const int64_t* __restrict__ n_dev, int ts2,
                                      uint64_t* keys, int32_t* vals, uint32_t mask,
                                      uint32_t* __restrict__ slot_of) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = *n_dev;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(coords)[i];
   const uint64_t key = pack_key(c.x, floor_div(c.y, ts2) * ts2, floor_div(c.z, ts2) * ts2,
@@ -287,22 +312,27 @@ __global__ void stride_insert_kernel(const int32_t* __restrict__ coords, int64_t
 }
 
 // pass 2: first-occurrence flags (0 = this row is the lowest child of its parent, -1 otherwise)
-__global__ void stride_flag_kernel(int64_t n, const int32_t* __restrict__ vals,
+__global__ void stride_flag_kernel(int64_t n, const int64_t* __restrict__ n_dev, const int32_t* __restrict__ vals,
                                    const uint32_t* __restrict__ slot_of,
                                    int32_t* __restrict__ flags) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (n_dev && i >= *n_dev) {  // between the actual count and the launch bound: never a first occurrence
+    flags[i] = -1;
+    return;
+  }
   flags[i] = (vals[slot_of[i]] == (int32_t)i) ? 0 : -1;
 }
 
 // pass 3: parent row of every fine row; coordinates of the coarse rows
-__global__ void stride_parent_kernel(const int32_t* __restrict__ coords, int64_t n, int ts2,
+__global__ void stride_parent_kernel(const int32_t* __restrict__ coords, int64_t n, const int64_t* __restrict__ n_dev, int ts2,
                                      const int32_t* __restrict__ vals,
                                      const uint32_t* __restrict__ slot_of,
                                      const int32_t* __restrict__ pos,
                                      int32_t* __restrict__ parent,
                                      int32_t* __restrict__ coarse_coords) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = *n_dev;
   if (i >= n) return;
   const int32_t first_child = vals[slot_of[i]];
   const int32_t row = pos[first_child];
@@ -316,12 +346,24 @@ __global__ void stride_parent_kernel(const int32_t* __restrict__ coords, int64_t
 }
 
 // pass 4: table values become coarse row ids
-__global__ void stride_relabel_kernel(int64_t n, const int32_t* __restrict__ flags,
+__global__ void stride_relabel_kernel(int64_t n, const int64_t* __restrict__ n_dev, const int32_t* __restrict__ flags,
                                       const uint32_t* __restrict__ slot_of,
                                       const int32_t* __restrict__ pos, int32_t* vals) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = *n_dev;
   if (i >= n) return;
   if (flags[i] == 0) vals[slot_of[i]] = pos[i];
+}
+
+// level chain on the device: counts[l] = rows of level l, counts[kMaxLevels + l] = rows of its first segment (-1: none)
+__global__ void chain_init_kernel(int64_t* counts, int64_t n0, int64_t split0) {
+  counts[0] = n0;
+  counts[kMaxLevels] = split0;
+}
+// segment boundary of the coarse level = number of first occurrences among the fine rows [0, split) = pos[split]
+__global__ void chain_split_kernel(const int32_t* __restrict__ pos, int64_t* counts, int l) {
+  const int64_t n = counts[l], fs = counts[kMaxLevels + l], nc = counts[l + 1];
+  counts[kMaxLevels + l + 1] = fs < 0 ? -1 : (fs > 0 && fs < n ? (int64_t)pos[fs] : (fs >= n ? nc : 0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,8 +481,9 @@ static void fill_offsets(int ksize, int region, int32_t (*o)[3], int* K_out) {
   *K_out = K;
 }
 
+// small synchronous read-back: 8-byte scalars land in h_pinned[0], a map's K + 1 offsets in its slot area
 static int read_back(pcmi_coords* h, const void* dev, size_t bytes, hipStream_t st) {
-  PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned, dev, bytes, hipMemcpyDeviceToHost, st));
+  PCMI_HIP_CHECK(hipMemcpyAsync(bytes <= 16 ? h->h_pinned : h->h_pinned + kMapSlot0, dev, bytes, hipMemcpyDeviceToHost, st));
   PCMI_HIP_CHECK(hipStreamSynchronize(st));
   return PCMI_OK;
 }
@@ -482,21 +525,26 @@ int pcmi_device_info(int* n_cu, char* arch_host, int arch_len) {
 int pcmi_coords_create(int dimension, pcmi_coords_t** out) {
   PCMI_REQUIRE(dimension == 3 && out, PCMI_ERR_UNSUPPORTED, "coords: only D=3 is on the hot path");
   pcmi_coords* h = new pcmi_coords();
-  if (hipMalloc((void**)&h->d_flags, 64) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_pinned, 4096) != hipSuccess) {
+  if (hipMalloc((void**)&h->d_flags, 64 + sizeof(int64_t) * 2 * kMaxLevels) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_pinned, 4096) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_counts, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_plan, hipEventDisableTiming) != hipSuccess) {
     set_error("coords_create: allocation failed");
-    delete h;
+    pcmi_coords_destroy(h);
     return PCMI_ERR_HIP;
   }
   h->d_total = (int64_t*)(h->d_flags + 8);
+  h->d_counts = (int64_t*)(h->d_flags + 16);
   *out = h;
   return PCMI_OK;
 }
 
 int pcmi_coords_destroy(pcmi_coords_t* h) {
   if (!h) return PCMI_OK;
-  (void)hipFree(h->d_flags);
-  (void)hipHostFree(h->h_pinned);
+  if (h->d_flags) (void)hipFree(h->d_flags);
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->ev_counts) (void)hipEventDestroy(h->ev_counts);
+  if (h->ev_plan) (void)hipEventDestroy(h->ev_plan);
   delete h;
   return PCMI_OK;
 }
@@ -507,6 +555,8 @@ int pcmi_coords_reset(pcmi_coords_t* h) {
   h->maps.clear();
   h->pending.clear();
   h->defer_maps = false;
+  h->plan_recorded = false;
+  h->insert_unchecked = false;
   h->persistent.reset();
   h->scratch.reset();
   return PCMI_OK;
@@ -518,7 +568,7 @@ int pcmi_coords_arena_bytes(pcmi_coords_t* h, size_t* bytes) {
   return PCMI_OK;
 }
 
-int pcmi_coords_insert(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream) {
+static int coords_insert_impl(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream, bool deferred) {
   PCMI_REQUIRE(h && (bxyz || n == 0) && n >= 0, PCMI_ERR_INVALID, "coords_insert: bad argument");
   PCMI_REQUIRE(h->levels.empty(), PCMI_ERR_INVALID, "coords_insert: handle already holds key 0 (reset first)");
   PCMI_REQUIRE(n < (1ll << 30), PCMI_ERR_RANGE, "coords_insert: too many rows");
@@ -538,13 +588,30 @@ int pcmi_coords_insert(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_st
                                                                    L.cap - 1, h->d_flags);
     PCMI_LAUNCH_CHECK();
   }
-  rc = read_back(h, h->d_flags, 8, st);
-  if (rc) return rc;
-  const int32_t* f = (const int32_t*)h->h_pinned;
-  PCMI_REQUIRE(f[1] == 0, PCMI_ERR_RANGE, "coords_insert: %d rows outside the packable range", f[1]);
-  PCMI_REQUIRE(f[0] == 0, PCMI_ERR_DUPLICATE, "coords_insert: %d duplicate coordinates", f[0]);
+  // the status words travel to their pinned slot; the host looks at them behind the next synchronisation of `st`
+  PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kStatusSlot, h->d_flags, 8, hipMemcpyDeviceToHost, st));
+  h->insert_unchecked = true;
   h->levels.push_back(L);
-  return PCMI_OK;
+  if (deferred) return PCMI_OK;
+  PCMI_HIP_CHECK(hipStreamSynchronize(st));
+  rc = check_insert_status(h);
+  if (rc) h->levels.clear();
+  return rc;
+}
+
+int pcmi_coords_insert(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream) {
+  return coords_insert_impl(h, bxyz, n, stream, false);
+}
+
+int pcmi_coords_insert_deferred(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, pcmi_stream_t stream) {
+  return coords_insert_impl(h, bxyz, n, stream, true);
+}
+
+int pcmi_coords_check(pcmi_coords_t* h, pcmi_stream_t stream) {
+  PCMI_REQUIRE(h, PCMI_ERR_INVALID, "null handle");
+  if (!h->insert_unchecked) return PCMI_OK;
+  PCMI_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+  return check_insert_status(h);
 }
 
 int pcmi_coords_size(pcmi_coords_t* h, int key, int64_t* n, int* tensor_stride) {
@@ -614,9 +681,9 @@ int pcmi_coords_stride(pcmi_coords_t* h, int in_key, int stride, int* out_key, i
   if (!parent || !slot_of || !flags || !pos) return PCMI_ERR_HIP;
   const int32_t* fine = h->levels[in_key].coords;
   const dim3 grid((unsigned)std::max<int64_t>(ceil_div(n, 256), 1));
-  stride_insert_kernel<<<grid, 256, 0, st>>>(fine, n, ts2, C.hkeys, C.hvals, C.cap - 1, slot_of);
+  stride_insert_kernel<<<grid, 256, 0, st>>>(fine, n, nullptr, ts2, C.hkeys, C.hvals, C.cap - 1, slot_of);
   PCMI_LAUNCH_CHECK();
-  stride_flag_kernel<<<grid, 256, 0, st>>>(n, C.hvals, slot_of, flags);
+  stride_flag_kernel<<<grid, 256, 0, st>>>(n, nullptr, C.hvals, slot_of, flags);
   PCMI_LAUNCH_CHECK();
   rc = exclusive_scan<true>(flags, n, pos, h->d_total, h->scratch, st);
   if (rc) return rc;
@@ -629,13 +696,15 @@ int pcmi_coords_stride(pcmi_coords_t* h, int in_key, int stride, int* out_key, i
   if (carry) PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + 1, pos + fsplit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   rc = read_back(h, h->d_total, 8, st);
   if (rc) return rc;
+  rc = check_insert_status(h);
+  if (rc) return rc;
   C.n = h->h_pinned[0];
   C.split = fsplit < 0 ? -1 : (carry ? (int64_t)(h->h_pinned[1] & 0xFFFFFFFFll) : (fsplit >= n ? C.n : 0));
   C.coords = h->persistent.alloc_n<int32_t>(C.n * 4);
   if (!C.coords) return PCMI_ERR_HIP;
-  stride_parent_kernel<<<grid, 256, 0, st>>>(fine, n, ts2, C.hvals, slot_of, pos, parent, C.coords);
+  stride_parent_kernel<<<grid, 256, 0, st>>>(fine, n, nullptr, ts2, C.hvals, slot_of, pos, parent, C.coords);
   PCMI_LAUNCH_CHECK();
-  stride_relabel_kernel<<<grid, 256, 0, st>>>(n, flags, slot_of, pos, C.hvals);
+  stride_relabel_kernel<<<grid, 256, 0, st>>>(n, nullptr, flags, slot_of, pos, C.hvals);
   PCMI_LAUNCH_CHECK();
   h->levels.push_back(C);
   const int ck = (int)h->levels.size() - 1;
@@ -657,8 +726,12 @@ int pcmi_kernel_offsets(int kernel_size, int region, int32_t* out_host, int* K) 
   return PCMI_OK;
 }
 
-int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, int stride, int region,
-                  pcmi_kmap_t* out, pcmi_stream_t stream) {
+}  // extern "C"
+
+// nosync: a map the plan built is returned as it is (M == -1 while its counts are on their way); the kernels of this
+// library do not need them (pcmi_net_forward uses this form)
+static int kmap_get_impl(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, int stride, int region,
+                         pcmi_kmap_t* out, pcmi_stream_t stream, bool nosync) {
   PCMI_REQUIRE(h && out, PCMI_ERR_INVALID, "kmap_get: null argument");
   PCMI_REQUIRE(in_key >= 0 && in_key < (int)h->levels.size() && out_key >= 0 && out_key < (int)h->levels.size(),
                PCMI_ERR_NOKEY, "kmap_get: unknown key (%d -> %d)", in_key, out_key);
@@ -670,6 +743,10 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
   for (auto& e : h->maps)
     if (e.in_key == in_key && e.out_key == out_key && e.ksize == kernel_size && e.stride == stride &&
         e.region == region) {
+      if (e.map.M < 0 && !h->defer_maps && !nosync) {  // built by the plan: the caller wants the host-side counts
+        const int rc0 = resolve_pending_maps(h);
+        if (rc0) return rc0;
+      }
       *out = e.map;
       return PCMI_OK;
     }
@@ -732,23 +809,20 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
     kmap_compact_kernel<<<dim3((unsigned)ceil_div(tot, 256)), 256, 0, st>>>(nbr, K, n_out, pos, h->d_total,
                                                                            pair_in, pair_out, offs);
     PCMI_LAUNCH_CHECK();
-    if (h->defer_maps) {
-      if ((int)h->pending.size() >= kMapSlots) {
-        rc = resolve_pending_maps(h, st);
-        if (rc) return rc;
-      }
-      defer_slot = (int)h->pending.size();
-      PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kMapSlot0 + (size_t)defer_slot * kMapSlotLen, offs, sizeof(int64_t) * (K + 1),
-                                    hipMemcpyDeviceToHost, st));
-    } else {
-      rc = read_back(h, offs, sizeof(int64_t) * (K + 1), st);
+    // the K + 1 offsets travel to this map's slot of the pinned buffer; a deferred build (pcmi_coords_plan_unet) does
+    // not wait for them, any other build synchronises here and fills in every map that is still waiting
+    if ((int)h->pending.size() >= kMapSlots) {
+      rc = resolve_pending_maps(h);
       if (rc) return rc;
-      memcpy(m.offs_host, h->h_pinned, sizeof(int64_t) * (K + 1));
     }
+    defer_slot = (int)h->pending.size();
+    PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kMapSlot0 + (size_t)defer_slot * kMapSlotLen, offs, sizeof(int64_t) * (K + 1),
+                                  hipMemcpyDeviceToHost, st));
+    PCMI_HIP_CHECK(hipEventRecord(h->ev_counts, st));
   } else {
     PCMI_HIP_CHECK(hipMemsetAsync(offs, 0, sizeof(int64_t) * (K + 1), st));
   }
-  m.M = m.offs_host[K];
+  m.M = defer_slot >= 0 ? -1 : 0;  // -1: the host-side counts are still on their way (see pcmi_kmap_t)
   m.perm = nullptr;
   m.nbr_perm = nullptr;
   m.tile_mask = nullptr;
@@ -784,13 +858,39 @@ int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, in
   m.offs = offs;
   h->maps.push_back({in_key, out_key, kernel_size, stride, region, m});
   if (defer_slot >= 0) h->pending.push_back({(int)h->maps.size() - 1, defer_slot});
-  *out = m;  // (deferred: offs_host / M are not filled in yet -- pcmi_coords_plan_unet discards this copy)
+  if (defer_slot >= 0 && !h->defer_maps) {
+    rc = resolve_pending_maps(h);
+    if (rc) return rc;
+    rc = check_insert_status(h);
+    if (rc) return rc;
+  }
+  *out = h->maps.back().map;  // (deferred build: offs_host / M are not filled in, M == -1)
   return PCMI_OK;
+}
+
+namespace pcmi {
+int kmap_get_nosync(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, int stride, int region, pcmi_kmap_t* out,
+                    pcmi_stream_t stream) {
+  return kmap_get_impl(h, in_key, out_key, kernel_size, stride, region, out, stream, true);
+}
+// makes `stream` wait for the end of the handle's last pcmi_coords_plan_unet (enqueued on another stream, unsynchronised)
+int coords_wait_plan(pcmi_coords_t* h, hipStream_t st) {
+  if (h && h->plan_recorded) PCMI_HIP_CHECK(hipStreamWaitEvent(st, h->ev_plan, 0));
+  return PCMI_OK;
+}
+}  // namespace pcmi
+
+extern "C" {
+
+int pcmi_kmap_get(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, int stride, int region,
+                  pcmi_kmap_t* out, pcmi_stream_t stream) {
+  return kmap_get_impl(h, in_key, out_key, kernel_size, stride, region, out, stream, false);
 }
 
 int pcmi_kmap_export(const pcmi_kmap_t* map, int32_t* nbr, int32_t* pair_in, int32_t* pair_out,
                      pcmi_stream_t stream) {
   PCMI_REQUIRE(map, PCMI_ERR_INVALID, "kmap_export: null map");
+  PCMI_REQUIRE(map->M >= 0, PCMI_ERR_INVALID, "kmap_export: the map's pair counts are not on the host yet (take it from pcmi_kmap_get)");
   hipStream_t st = as_stream(stream);
   const size_t tot = (size_t)map->K * map->n_out;
   if (nbr && tot) PCMI_HIP_CHECK(hipMemcpyAsync(nbr, map->nbr, sizeof(int32_t) * tot, hipMemcpyDeviceToDevice, st));
@@ -801,41 +901,107 @@ int pcmi_kmap_export(const pcmi_kmap_t* map, int32_t* nbr, int32_t* pair_in, int
   return PCMI_OK;
 }
 
+}  // extern "C"
+
+// Strided levels 1 .. n_down of a fresh handle (key 0 only) WITHOUT a read-back per level: every level is sized by its
+// bound (a coarse level has at most as many rows as the level above it, hence at most n0), its kernels take the actual
+// count from the device (counts[l], written by the scan of the level above), and the counts of all levels plus the
+// insert's status words come back in ONE synchronisation at the end.  Same tables, same row order as pcmi_coords_stride.
+static int build_level_chain(pcmi_coords_t* h, int n_down, hipStream_t st) {
+  const int64_t n0 = h->levels[0].n;
+  chain_init_kernel<<<1, 1, 0, st>>>(h->d_counts, n0, h->levels[0].split);
+  PCMI_LAUNCH_CHECK();
+  const dim3 grid((unsigned)std::max<int64_t>(ceil_div(n0, 256), 1));
+  std::vector<int32_t*> parents;
+  for (int l = 0; l < n_down; ++l) {
+    h->scratch.reset();
+    const Level& F = h->levels[l];
+    Level C;
+    C.ts = F.ts * 2;
+    int rc = new_table(h, C, n0, st);
+    if (rc) return rc;
+    int32_t* parent = h->persistent.alloc_n<int32_t>(n0);
+    C.coords = h->persistent.alloc_n<int32_t>(n0 * 4);
+    uint32_t* slot_of = h->scratch.alloc_n<uint32_t>(n0);
+    int32_t* flags = h->scratch.alloc_n<int32_t>(n0);
+    int32_t* pos = h->scratch.alloc_n<int32_t>(n0);
+    if (!parent || !C.coords || !slot_of || !flags || !pos) return PCMI_ERR_HIP;
+    const int64_t* n_dev = h->d_counts + l;
+    stride_insert_kernel<<<grid, 256, 0, st>>>(F.coords, n0, n_dev, C.ts, C.hkeys, C.hvals, C.cap - 1, slot_of);
+    PCMI_LAUNCH_CHECK();
+    stride_flag_kernel<<<grid, 256, 0, st>>>(n0, n_dev, C.hvals, slot_of, flags);
+    PCMI_LAUNCH_CHECK();
+    rc = exclusive_scan<true>(flags, n0, pos, h->d_counts + l + 1, h->scratch, st);
+    if (rc) return rc;
+    chain_split_kernel<<<1, 1, 0, st>>>(pos, h->d_counts, l);
+    PCMI_LAUNCH_CHECK();
+    stride_parent_kernel<<<grid, 256, 0, st>>>(F.coords, n0, n_dev, C.ts, C.hvals, slot_of, pos, parent, C.coords);
+    PCMI_LAUNCH_CHECK();
+    stride_relabel_kernel<<<grid, 256, 0, st>>>(n0, n_dev, flags, slot_of, pos, C.hvals);
+    PCMI_LAUNCH_CHECK();
+    C.n = -1;  // known after the read-back below
+    h->levels.push_back(C);
+    parents.push_back(parent);
+  }
+  PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kLevelSlot0, h->d_counts, sizeof(int64_t) * 2 * kMaxLevels, hipMemcpyDeviceToHost, st));
+  PCMI_HIP_CHECK(hipStreamSynchronize(st));
+  int rc = check_insert_status(h);
+  if (rc) {
+    h->levels.resize(1);
+    return rc;
+  }
+  for (int l = 0; l < n_down; ++l) {
+    h->levels[l + 1].n = h->h_pinned[kLevelSlot0 + l + 1];
+    h->levels[l + 1].split = h->h_pinned[kLevelSlot0 + kMaxLevels + l + 1];
+    h->levels[l].parent = parents[l];
+    h->levels[l].child_key = l + 1;
+  }
+  return PCMI_OK;
+}
+
+extern "C" {
+
 int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int block_region,
                           pcmi_stream_t stream) {
   PCMI_REQUIRE(h && !h->levels.empty(), PCMI_ERR_INVALID, "plan_unet: insert coordinates first");
-  PCMI_REQUIRE(n_down >= 0 && n_down <= 8, PCMI_ERR_INVALID, "plan_unet: bad depth");
+  PCMI_REQUIRE(n_down >= 0 && n_down < kMaxLevels - 1 && n_down <= 8, PCMI_ERR_INVALID, "plan_unet: bad depth");
+  hipStream_t st = as_stream(stream);
   pcmi_kmap_t tmp;
-  int key = 0;
-  // PCMI_PLAN_DEFER=1 (off by default until it has been through the GPU suite): one synchronisation for the pair counts
-  // of all the maps instead of one per map -- each of them otherwise waits for a free compute unit behind the
-  // compute streams' resident workgroups ("Host side of the iteration")
-  const char* de = getenv("PCMI_PLAN_DEFER");
-  struct Defer {  // also on the error paths: a later pcmi_kmap_get must never find a map without its counts
+  int rc;
+  // ---- levels: one synchronisation for the whole chain (PCMI_PLAN_CHAIN=0: one per level, as pcmi_coords_stride) ----
+  static const bool chain = [] {
+    const char* e = getenv("PCMI_PLAN_CHAIN");
+    return !(e && e[0] == '0');
+  }();
+  if (chain && h->levels.size() == 1 && n_down > 0 && h->maps.empty()) {
+    rc = build_level_chain(h, n_down, st);
+    if (rc) return rc;
+  }
+  // ---- maps: built on `st` without waiting for their pair counts (see pcmi_coords::defer_maps) -------------------------
+  struct Defer {  // also on the error paths: the flag never outlives the call
     pcmi_coords_t* h;
-    hipStream_t st;
-    ~Defer() {
-      (void)resolve_pending_maps(h, st);
-      h->defer_maps = false;
-    }
-  } defer{h, as_stream(stream)};
-  h->defer_maps = de && de[0] == '1';
-  int rc = pcmi_kmap_get(h, 0, 0, 3, 1, first_region, &tmp, stream);
+    ~Defer() { h->defer_maps = false; }
+  } defer{h};
+  h->defer_maps = true;
+  int key = 0;
+  rc = kmap_get_impl(h, 0, 0, 3, 1, first_region, &tmp, stream, true);
   if (rc) return rc;
   for (int l = 0; l <= n_down; ++l) {
-    rc = pcmi_kmap_get(h, key, key, 3, 1, block_region, &tmp, stream);
+    rc = kmap_get_impl(h, key, key, 3, 1, block_region, &tmp, stream, true);
     if (rc) return rc;
     if (l == n_down) break;
     int ck;
     int64_t n;
     rc = pcmi_coords_stride(h, key, 2, &ck, &n, stream);
     if (rc) return rc;
-    rc = pcmi_kmap_get(h, key, ck, 2, 2, PCMI_REGION_HYPERCUBE, &tmp, stream);
+    rc = kmap_get_impl(h, key, ck, 2, 2, PCMI_REGION_HYPERCUBE, &tmp, stream, true);
     if (rc) return rc;
     key = ck;
   }
   h->defer_maps = false;
-  return resolve_pending_maps(h, as_stream(stream));
+  PCMI_HIP_CHECK(hipEventRecord(h->ev_plan, st));
+  h->plan_recorded = true;
+  return PCMI_OK;
 }
 
 }  // extern "C"

@@ -693,11 +693,14 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.valid = false;
   const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
   g_prof_fwd.start();
+  // the coordinate plan may have been enqueued on another stream without a host synchronisation behind it
+  int rc = coords_wait_plan(coords, st);
+  if (rc) return rc;
   // ---- level sizes (cache hits once the coordinate plan exists) ------------------------------------
   std::vector<int> keys(n.n_levels, 0);
   ps.rows.assign(n.n_levels, 0);
   int64_t n0 = 0;
-  int rc = pcmi_coords_size(coords, 0, &n0, nullptr);
+  rc = pcmi_coords_size(coords, 0, &n0, nullptr);
   if (rc) return rc;
   PCMI_REQUIRE(n0 == n_rows, PCMI_ERR_INVALID, "net_forward: %lld feature rows but %lld coordinates", (long long)n_rows,
                (long long)n0);
@@ -727,17 +730,17 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     if (op.type == PCMI_OP_CONV && op.kernel_size > 1) {
       if (!op.transpose && op.stride == 1) {
         PCMI_REQUIRE(li == lo, PCMI_ERR_INVALID, "net: op %d: stride-1 conv across levels", i);
-        rc = pcmi_kmap_get(coords, keys[li], keys[li], op.kernel_size, 1, op.region, &ps.maps[i], stream);
+        rc = kmap_get_nosync(coords, keys[li], keys[li], op.kernel_size, 1, op.region, &ps.maps[i], stream);
       } else if (!op.transpose) {
         PCMI_REQUIRE(lo == li + 1, PCMI_ERR_INVALID, "net: op %d: strided conv must go one level down", i);
-        rc = pcmi_kmap_get(coords, keys[li], keys[lo], op.kernel_size, op.stride, op.region, &ps.maps[i], stream);
+        rc = kmap_get_nosync(coords, keys[li], keys[lo], op.kernel_size, op.stride, op.region, &ps.maps[i], stream);
       } else {
         PCMI_REQUIRE(lo == li - 1, PCMI_ERR_INVALID, "net: op %d: transposed conv must go one level up", i);
-        rc = pcmi_kmap_get(coords, keys[lo], keys[li], op.kernel_size, op.stride, op.region, &ps.maps[i], stream);
+        rc = kmap_get_nosync(coords, keys[lo], keys[li], op.kernel_size, op.stride, op.region, &ps.maps[i], stream);
       }
       if (rc) return rc;
       ps.has_map[i] = 1;
-      M = ps.maps[i].M;
+      M = kmap_pairs_bound(ps.maps[i]);
     }
     ws_need = std::max(ws_need, op_workspace(op, ps.rows[li], ps.rows[lo], M));
   }

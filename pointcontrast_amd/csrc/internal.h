@@ -55,6 +55,18 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
                  float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
 int bn_running_update(const BnRunningUpdate* table_dev, int n_entries, hipStream_t st);
 
+// coords.hip: a cached map as it is -- M == -1 / offs_host unset when pcmi_coords_plan_unet built it and nobody has asked
+// for the counts yet (the kernels size their launches by bounds and read the device-side offsets); and the ordering of a
+// consumer stream behind the handle's last plan
+int kmap_get_nosync(pcmi_coords_t* h, int in_key, int out_key, int kernel_size, int stride, int region, pcmi_kmap_t* out,
+                    pcmi_stream_t stream);
+int coords_wait_plan(pcmi_coords_t* h, hipStream_t st);
+// pairs of a map as far as the host knows: exact once the counts have arrived, else the bound (every output row of a
+// stride-1 map has at most K neighbours; every fine row of a stride-2 map exactly one parent)
+static inline int64_t kmap_pairs_bound(const pcmi_kmap_t& m) {
+  return m.M >= 0 ? m.M : (m.stride == 1 ? (int64_t)m.K * m.n_out : m.n_in);
+}
+
 size_t sort_rows_temp_bytes(int64_t n);
 int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, uint32_t* mask_in, uint32_t* mask_out,
                       int32_t* iota, void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st);

@@ -1478,8 +1478,13 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     a.offs = map->offs;
     Plan p = make_plan(n_rows, N, a.K, true);
     const int TM = 32 * p.RW;
+    // tiles of all offsets: exact when the map's counts are on the host, else their bound (every pair is one fine row
+    // and every offset adds at most one ragged tile); a workgroup past the last tile leaves at once
     int64_t tiles = 0;
-    for (int k = 0; k < a.K; ++k) tiles += ceil_div(map->offs_host[k + 1] - map->offs_host[k], TM);
+    if (map->M >= 0)
+      for (int k = 0; k < a.K; ++k) tiles += ceil_div(map->offs_host[k + 1] - map->offs_host[k], TM);
+    else
+      tiles = ceil_div(kmap_pairs_bound(*map), TM) + a.K;
     if (tiles == 0) return PCMI_OK;
     dim3 grid((unsigned)tiles, (unsigned)(N / (32 * p.NT)), 1);
     return w_transposed ? launch_rw<true, true>(p.RW, p.NT, a, grid, st)

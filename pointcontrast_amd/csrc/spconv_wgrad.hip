@@ -32,8 +32,11 @@ struct WgradArgs {
   int64_t M;
   int K;
   int cin, cout;
-  int chunk;        // pairs per workgroup (multiple of 256)
-  float* slabs;     // [n_chunks][cin][cout]
+  int chunk;        // pairs per workgroup (multiple of 128)
+  int mpk;          // maps: chunk slots per offset = ceil(bound of the pairs of one offset / chunk); workgroup b takes
+                    // chunk b % mpk of offset b / mpk and leaves at once if that offset has fewer chunks -- the launch is
+                    // sized without the host knowing the per-offset pair counts (they are read from `offs` on the device)
+  float* slabs;     // [n_chunks][cin][cout]  (maps: slot k * mpk + j)
   // how the chunks of an offset become gW[k] (chosen on the host from the per-offset chunk counts):
   //   kSlabs  : every workgroup writes its slab, wgrad_reduce_kernel sums them (many chunks per offset: level 1)
   //   kDirect : no offset has more than one chunk -> the workgroup stores / accumulates straight into gW (levels 4+)
@@ -118,35 +121,25 @@ struct BufLoad<4> {
   }
 };
 
-// chunk c of the launch -> (offset k, first pair, last pair); first_chunk / n_chunks: the chunks of that offset
-__device__ inline void locate_chunk(const int64_t* offs, int K, int64_t M, int chunk, int64_t c,
-                                    int* k_out, int64_t* pb, int64_t* pe, int64_t* first_chunk = nullptr,
-                                    int64_t* n_chunks = nullptr) {
+// workgroup c of the launch -> its chunk: desc = {offset k (-1: nothing to do), first pair, end, first slab of that
+// offset, number of chunks of that offset}.  Dense (offs == nullptr): one group of M pairs, chunk c.
+__device__ inline void locate_chunk(const int64_t* offs, int mpk, int64_t M, int chunk, int64_t c, int64_t* desc) {
   if (!offs) {
-    *k_out = 0;
-    *pb = c * chunk;
-    *pe = min(*pb + (int64_t)chunk, M);
-    if (first_chunk) *first_chunk = 0;
-    if (n_chunks) *n_chunks = (M + chunk - 1) / chunk;
+    desc[0] = c * chunk < M ? 0 : -1;
+    desc[1] = c * chunk;
+    desc[2] = min(desc[1] + (int64_t)chunk, M);
+    desc[3] = 0;
+    desc[4] = (M + chunk - 1) / chunk;
     return;
   }
-  int64_t first = 0;
-  for (int k = 0; k < K; ++k) {
-    const int64_t b = offs[k], e = offs[k + 1];
-    const int64_t nc = (e - b + chunk - 1) / chunk;
-    if (c < nc) {
-      *k_out = k;
-      *pb = b + c * chunk;
-      *pe = min(*pb + (int64_t)chunk, e);
-      if (first_chunk) *first_chunk = first;
-      if (n_chunks) *n_chunks = nc;
-      return;
-    }
-    c -= nc;
-    first += nc;
-  }
-  *k_out = -1;
-  *pb = *pe = 0;
+  const int64_t k = c / mpk, j = c - k * mpk;
+  const int64_t b = offs[k], e = offs[k + 1];
+  const int64_t pb = b + j * chunk;
+  desc[0] = pb < e ? k : -1;
+  desc[1] = pb;
+  desc[2] = min(pb + (int64_t)chunk, e);
+  desc[3] = k * mpk;
+  desc[4] = (e - b + chunk - 1) / chunk;
 }
 
 #ifndef PCMI_ABLATE
@@ -211,9 +204,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   const int i = lane & 31, h = lane >> 5;
   const int c0 = blockIdx.y * 32 * CT, n0 = blockIdx.z * 32 * NT;
   WPROF(w_t0);
-  if (wave == 0) {
-    locate_chunk_wave(a.offs, a.K, a.M, a.chunk, blockIdx.x, lane, s_desc);
-    if (lane == 0) s_desc[5] = blockIdx.x;  // slab of this chunk
+  if (t == 0) {
+    locate_chunk(a.offs, a.mpk, a.M, a.chunk, blockIdx.x, s_desc);
+    s_desc[5] = blockIdx.x;  // slab of this chunk
   }
   __syncthreads();
   if (s_desc[0] < 0) return;
@@ -492,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 //             level 1, dense 1x1 convs), so the serial chain of dependent loads is 8x shorter.
 template <int LANES>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
-                                                           const int64_t* __restrict__ offs, int K, int64_t M,
+                                                           const int64_t* __restrict__ offs, int mpk, int64_t M,
                                                            int chunk, int64_t per_k /* cin*cout */,
                                                            float* __restrict__ gw, int accumulate) {
   __shared__ float s_part[LANES][33];
@@ -503,8 +496,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   int64_t first = 0, count;
   if (!offs) {
     count = (M + chunk - 1) / chunk;
-  } else {
-    for (int kk = 0; kk < k; ++kk) first += (offs[kk + 1] - offs[kk] + chunk - 1) / chunk;
+  } else {  // the slabs of offset k sit in slots k * mpk ... (see WgradArgs::mpk)
+    first = (int64_t)k * mpk;
     count = (offs[k + 1] - offs[k] + chunk - 1) / chunk;
   }
   float s = 0.f;
@@ -527,16 +520,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(WgradArgs a) {
   __shared__ float s_part[8][CIN][33];
-  __shared__ int64_t s_desc[3];
+  __shared__ int64_t s_desc[5];
   const int t = threadIdx.x;
-  if (t == 0) {
-    int k;
-    int64_t pb, pe;
-    locate_chunk(a.offs, a.K, a.M, a.chunk, blockIdx.x, &k, &pb, &pe);
-    s_desc[0] = k;
-    s_desc[1] = pb;
-    s_desc[2] = pe;
-  }
+  if (t == 0) locate_chunk(a.offs, a.mpk, a.M, a.chunk, blockIdx.x, s_desc);
   __syncthreads();
   if (s_desc[0] < 0) return;
   const int64_t pb = s_desc[1], pe = s_desc[2];
@@ -680,10 +666,25 @@ static int wgrad_min_chunk(int64_t M) {
   return (int)std::max<int64_t>(kWgradMinChunk, align_up((size_t)ceil_div(M, kWgradMaxChunks), 128));
 }
 
-static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk);
+// Pairs one offset of a map can have at most: a row takes part in at most one pair per offset on either side.
+static int64_t wgrad_offset_bound(int64_t n_in, int64_t n_out) { return std::min(n_in, n_out); }
 
-static int wgrad_chunk(const pcmi_kmap_t* map, int64_t M, int64_t wgs_per_chunk, int64_t slots) {
-  const int lo = wgrad_min_chunk(M);
+// Pairs of offset k as far as the host knows (only steers the chunk size): exact once the map's counts have arrived,
+// otherwise the typical occupancy of a surface (17 of 27 neighbours) / an even split of the fine rows over the 8 children.
+static int64_t wgrad_offset_len(const pcmi_kmap_t* map, int k) {
+  if (map->M >= 0) return map->offs_host[k + 1] - map->offs_host[k];
+  return map->stride == 1 ? map->n_out * 17 / 27 : ceil_div(map->n_in, map->K);
+}
+
+static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk) {
+  if (!map) return ceil_div(M, chunk);
+  int64_t n = 0;
+  for (int k = 0; k < map->K; ++k) n += ceil_div(wgrad_offset_len(map, k), chunk);
+  return n;
+}
+
+// lo: smallest admissible chunk (keeps the number of chunk slots bounded, see spconv_wgrad_workspace)
+static int wgrad_chunk(const pcmi_kmap_t* map, int64_t M, int lo, int64_t wgs_per_chunk, int64_t slots) {
   int64_t best_cost = -1;
   for (int c = std::max(lo, wgrad_max_chunk()); c >= lo; c -= 128) {
     const int64_t cost = ceil_div(wgrad_num_chunks(map, M, c) * wgs_per_chunk, slots) * ceil_div(c, 256);
@@ -697,17 +698,17 @@ static int wgrad_chunk(const pcmi_kmap_t* map, int64_t M, int64_t wgs_per_chunk,
   return lo;
 }
 
-static int64_t wgrad_num_chunks(const pcmi_kmap_t* map, int64_t M, int chunk) {
-  if (!map) return ceil_div(M, chunk);
-  int64_t n = 0;
-  for (int k = 0; k < map->K; ++k) n += ceil_div(map->offs_host[k + 1] - map->offs_host[k], chunk);
-  return n;
+// Slab slots of a launch: K * ceil(offset bound / chunk) for a map (WgradArgs::mpk), ceil(M / chunk) for the dense case;
+// the smallest chunk a launch may pick keeps them under ~4096 + K.
+static int wgrad_lo_chunk(int64_t n_in, int64_t n_out, int K, int64_t M) {
+  return K > 1 ? wgrad_min_chunk(wgrad_offset_bound(n_in, n_out) * K) : wgrad_min_chunk(M);
 }
 
 size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M) {
   if (M <= 0) M = std::max(n_in, n_out);
-  const int64_t nchunks = ceil_div(M, wgrad_min_chunk(M)) + K;
-  return (size_t)nchunks * cin * cout * sizeof(float) + (size_t)1024 * cout * sizeof(float);
+  const int lo = wgrad_lo_chunk(n_in, n_out, K, M);
+  const int64_t nchunks = K > 1 ? (int64_t)K * ceil_div(wgrad_offset_bound(n_in, n_out), lo) : ceil_div(M, lo);
+  return (size_t)std::max<int64_t>(nchunks, 1) * cin * cout * sizeof(float) + (size_t)1024 * cout * sizeof(float);
 }
 
 }  // namespace pcmi
@@ -735,7 +736,7 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   if (map) {
     const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
     PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: rows do not match the map");
-    M = map->M;
+    M = kmap_pairs_bound(*map);  // exact once the map's counts are on the host; only sizing / early-outs use it
   } else {
     PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: dense path needs n_in == n_out");
     M = n_in;
@@ -775,14 +776,13 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
     wgs_per_chunk = (int64_t)(cin / (32 * CT)) * (cout / (32 * NT));
     slots = (int64_t)wgrad_occupancy(CT, NT, a.idx_x != nullptr) * num_cu();
   }
-  a.chunk = wgrad_chunk(map, M, wgs_per_chunk, slots);
-  const int64_t nchunks = wgrad_num_chunks(map, M, a.chunk);
-  int64_t max_per_k = 0, empty_k = 0;  // chunks of the busiest offset, offsets without pairs
-  for (int k = 0; k < K; ++k) {
-    const int64_t len = map ? map->offs_host[k + 1] - map->offs_host[k] : M;
-    max_per_k = std::max(max_per_k, ceil_div(len, a.chunk));
-    empty_k += len == 0;
-  }
+  // The launch is sized WITHOUT the per-offset pair counts (pcmi_coords_plan_unet leaves them on the device): every
+  // offset gets mpk = ceil(bound / chunk) chunk slots and a workgroup whose slot lies behind the offset's last pair
+  // leaves at once (WgradArgs::mpk).  The counts, when the host has them, only steer the chunk size.
+  a.chunk = wgrad_chunk(map, M, wgrad_lo_chunk(n_in, n_out, K, M), wgs_per_chunk, slots);
+  a.mpk = map ? (int)ceil_div(wgrad_offset_bound(n_in, n_out), a.chunk) : 0;
+  const int64_t nchunks = map ? (int64_t)K * a.mpk : ceil_div(M, a.chunk);
+  const int64_t max_per_k = map ? a.mpk : nchunks;  // bound of the chunks of one offset
   static const int arrive_max = [] {  // PCMI_WGRAD_ARRIVE_MAX: most chunks per offset the in-kernel reduction takes
     const char* e = getenv("PCMI_WGRAD_ARRIVE_MAX");
     return e ? atoi(e) : 8;
@@ -799,7 +799,7 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
     a.counters = stream_counters(st, (size_t)K * (cin / (32 * CT)) * (cout / (32 * NT)));
     if (!a.counters) return PCMI_ERR_HIP;
   }
-  if (a.mode != kSlabs && empty_k > 0 && !accumulate)  // offsets without pairs get no workgroup: their slices are zero
+  if (a.mode != kSlabs && map && !accumulate)  // an offset without pairs gets no workgroup: its slice must read zero
     PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
   const size_t slab_bytes = a.mode == kDirect ? 0 : (size_t)nchunks * per_k * sizeof(float);
   const size_t bias_bytes = gbias ? (size_t)1024 * cout * sizeof(float) : 0;
@@ -828,10 +828,10 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   if (a.mode != kSlabs) {
     // gW is complete when the launch is
   } else if (nchunks > 16 * (int64_t)K)
-    wgrad_reduce_kernel<8><<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
+    wgrad_reduce_kernel<8><<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, a.mpk, M, a.chunk,
                                                                                           per_k, gweight, accumulate);
   else
-    wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(per_k, 256), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, K, M, a.chunk,
+    wgrad_reduce_kernel<1><<<dim3((unsigned)ceil_div(per_k, 256), (unsigned)K), 256, 0, st>>>(a.slabs, a.offs, a.mpk, M, a.chunk,
                                                                                            per_k, gweight, accumulate);
   PCMI_LAUNCH_CHECK();
   if (gbias) {

@@ -163,7 +163,8 @@ class ContrastiveLossTrainer:
       C1[:, 0] += n_batch0
       Cj, Fj = torch.cat([C0, C1]), torch.cat([input_dict["sinput0_F"], input_dict["sinput1_F"]])
       sub("prep.concat")
-      sj = ME.SparseTensor(Fj, coords=Cj).to(self.cur_device)
+      # (defer_check: the insert's duplicate / range status comes back with plan_unet's one synchronisation)
+      sj = ME.SparseTensor(Fj, coords=Cj).to(self.cur_device, defer_check=True)
       sj.coords_man.set_split(C0.shape[0])
       sub("prep.upload_and_hash")
       sj.coords_man.plan_unet(self.engine.n_down)
@@ -173,8 +174,9 @@ class ContrastiveLossTrainer:
       sub("prep.pair_selection")
       return prep
     else:
-      s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device)
-      s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device)
+      planned = self.engine is not None
+      s0 = ME.SparseTensor(input_dict["sinput0_F"], coords=input_dict["sinput0_C"]).to(self.cur_device, defer_check=planned)
+      s1 = ME.SparseTensor(input_dict["sinput1_F"], coords=input_dict["sinput1_C"]).to(self.cur_device, defer_check=planned)
       if self.engine is not None:
         s0.coords_man.plan_unet(self.engine.n_down)
         s1.coords_man.plan_unet(self.engine.n_down)

@@ -102,11 +102,16 @@ class CoordsKey:
 class CoordsManager:
   """ME.CoordsManager on the device: hash, strided coordinate sets and kernel maps are
   HIP kernels (ME 0.4.x ran them on the CPU).  Coordinate work is enqueued on a side
-  ("plan") stream so that building the next SparseTensor's maps overlaps the compute stream;
-  every planning call is host-synchronous on that stream, so its results are visible to the
-  compute stream without further events."""
+  ("plan") stream so that building the next SparseTensor's maps overlaps the compute stream.
+  The per-call entry points (stride, kernel_map) are host-synchronous on that stream; plan_unet
+  synchronises once (level sizes) and leaves its maps enqueued -- the native engine orders its
+  stream behind the plan itself (pcmi_net_forward), per-layer callers get their maps through
+  kernel_map, which waits for what it hands out.
 
-  def __init__(self, coords, D=3):
+  defer_check: the insert is only enqueued; duplicate / out-of-range coordinates are then
+  reported by the next synchronising call (plan_unet, stride, kernel_map) or by check()."""
+
+  def __init__(self, coords, D=3, defer_check=False):
     assert D == 3
     require_cuda(coords, "CoordsManager")
     assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4, \
@@ -125,7 +130,13 @@ class CoordsManager:
       self._plan.wait_stream(torch.cuda.current_stream(self.device))
       c = coords.contiguous()
       c.record_stream(self._plan)
-      check(lib.pcmi_coords_insert(self._h, ptr(c), c.shape[0], self._st()))
+      insert = lib.pcmi_coords_insert_deferred if defer_check else lib.pcmi_coords_insert
+      check(insert(self._h, ptr(c), c.shape[0], self._st()))
+
+  def check(self):
+    """Reports a deferred insert's duplicate / out-of-range coordinates (synchronises the plan stream if needed)."""
+    with torch.cuda.device(self.device):
+      check(lib.pcmi_coords_check(self._h, self._st()))
 
   def _st(self):
     return C.c_void_p(self._plan.cuda_stream)
@@ -313,7 +324,8 @@ class SparseTensor:
         self._cpu_coords = coords
         self.coords_man, self.coords_key = None, None
 
-  def to(self, device):
+  def to(self, device, defer_check=False):
+    """defer_check: see CoordsManager (the caller plans the network right behind this call)."""
     device = torch.device(device if not isinstance(device, int) else "cuda:%d" % device)
     if self.coords_man is None:
       # Uploads and the coordinate hash run on the side ("plan") stream: they then never queue behind the
@@ -322,7 +334,7 @@ class SparseTensor:
       with torch.cuda.device(device), torch.cuda.stream(plan):
         c = self._cpu_coords.to(device, non_blocking=True)
         f = self._F.to(device, non_blocking=True)
-        cm = CoordsManager(c)
+        cm = CoordsManager(c, defer_check=defer_check)
       ev = torch.cuda.Event()
       ev.record(plan)
       f.record_stream(cur)

@@ -123,27 +123,27 @@ def test_maps_match_oracle_at_bench_and_1cm_sizes(ME):
   _check_maps(ME, big, levels=2)
 
 
-@pytest.mark.skipif(os.environ.get("PCMI_TEST_EXPERIMENTAL") != "1",
-                    reason="opt-in path that has not been on a GPU yet (written after the round's GPU budget was spent): "
-                           "PCMI_TEST_EXPERIMENTAL=1 runs it")
-def test_plan_with_deferred_read_backs_builds_the_same_maps(ME, monkeypatch):
-  """PCMI_PLAN_DEFER=1: pcmi_coords_plan_unet copies every map's per-offset pair counts to its own pinned slot and
-  synchronises ONCE at the end instead of once per map (11 of the 17 host read-backs of a batch).  Same tables, same
-  pair lists, same counts as the default plan -- on a two-segment batch of the bench's size class."""
+def test_plan_unet_builds_the_same_levels_and_maps_as_the_per_call_path(ME):
+  """pcmi_coords_plan_unet = ONE host synchronisation: the strided levels as a chain whose kernels take their row counts
+  from the device (sized by bounds), the maps enqueued without waiting for their pair counts, a deferred insert check.
+  Levels (sizes, segment boundaries, coordinates), tables, pair lists and counts must equal what the per-call entry
+  points (pcmi_coords_stride / pcmi_kmap_get, one synchronisation each) build -- on a two-segment batch of the bench's
+  size class."""
   from pointcontrast_amd.lib import synthetic
   b = synthetic.make_batch(seed=2, batch_size=2)
   C0, C1 = torch.from_numpy(b["sinput0_C"]), torch.from_numpy(b["sinput1_C"]).clone()
   C1[:, 0] += int(C0[:, 0].max()) + 1
   C = torch.cat([C0, C1])
   got = {}
-  for mode in ("0", "1"):
-    monkeypatch.setenv("PCMI_PLAN_DEFER", mode)
-    st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  for planned in (False, True):
+    st = ME.SparseTensor(torch.zeros((len(C), 4)), coords=C).to(DEV, defer_check=planned)
     cm = st.coords_man
     cm.set_split(C0.shape[0])
-    cm.plan_unet(4)
+    if planned:
+      cm.plan_unet(4)
     out, key = [], st.coords_key
     for lvl in range(5):
+      out.append((cm.size(key), cm.split(key), cm.get_coords(key).cpu()))
       m = cm.kernel_map(key, key, 3, 1, 3)
       nbr, pin, pout = cm.export_map(m)
       out.append((int(m.M), list(m.offs_host[:28]), nbr.cpu(), pin.cpu(), pout.cpu()))
@@ -154,12 +154,27 @@ def test_plan_with_deferred_read_backs_builds_the_same_maps(ME, monkeypatch):
       nbr2, pin2, pout2 = cm.export_map(m2)
       out.append((int(m2.M), list(m2.offs_host[:9]), nbr2.cpu(), pin2.cpu(), pout2.cpu()))
       key = ck
-    got[mode] = out
-  assert len(got["0"]) == len(got["1"]) == 9
-  for a, d in zip(got["0"], got["1"]):
-    assert a[0] == d[0] and a[0] > 0 and a[1] == d[1]
+    m0 = cm.kernel_map(st.coords_key, st.coords_key, 3, 1, 0)  # the stem's HYPERCUBE map
+    out.append((int(m0.M), list(m0.offs_host[:28])) + tuple(t.cpu() for t in cm.export_map(m0)))
+    got[planned] = out
+  assert len(got[False]) == len(got[True]) == 15
+  for a, d in zip(got[False], got[True]):
+    assert a[0] == d[0] and a[0] > 0 and a[1] == d[1], (a[:2], d[:2])
     for x, y in zip(a[2:], d[2:]):
       assert torch.equal(x, y)
+
+
+def test_deferred_insert_reports_duplicates_at_the_plan(ME):
+  """A deferred insert (the training step's form) reports duplicate coordinates at the next synchronising call."""
+  from pointcontrast_amd._lib import PcmiError
+  c = torch.tensor(random_coords(3000, seed=4))
+  c = torch.cat([c, c[100:101]])
+  st = ME.SparseTensor(torch.zeros((len(c), 4)), coords=c).to(DEV, defer_check=True)
+  with pytest.raises(PcmiError, match="duplicate"):
+    st.coords_man.plan_unet(2)
+  st2 = ME.SparseTensor(torch.zeros((len(c), 4)), coords=c).to(DEV, defer_check=True)
+  with pytest.raises(PcmiError, match="duplicate"):
+    st2.coords_man.check()
 
 
 def test_maps_random_negative_coords(ME):
