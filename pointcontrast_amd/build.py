@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libpcmi.so")
-SOURCES = ["coords.hip", "spconv.hip", "spconv_x3.hip", "spconv_wgrad.hip", "norm.hip", "loss.hip", "engine.hip", "sortrows.hip", "widths.hip", "loader.hip"]
+SOURCES = ["coords.hip", "spconv.hip", "spconv_x3.hip", "spconv_wgrad.hip", "spconv_wgrad_x3.hip", "norm.hip", "loss.hip", "engine.hip", "sortrows.hip", "widths.hip", "loader.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
          "-Wall", "-Wno-unused-function"] + os.environ.get("PCMI_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -37,7 +37,7 @@ def _digest(paths):
 
 def build_lib(force=False, verbose=False):
   os.makedirs(BUILD, exist_ok=True)
-  headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "spconv_args.h"), os.path.join(HERE, "..", "include", "pcmi.h")]
+  headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "spconv_args.h"), os.path.join(CSRC, "x3_split.h"), os.path.join(HERE, "..", "include", "pcmi.h")]
   hipcc = _hipcc()
 
   def compile_one(src):

@@ -67,6 +67,12 @@ static inline int64_t kmap_pairs_bound(const pcmi_kmap_t& m) {
   return m.M >= 0 ? m.M : (m.stride == 1 ? (int64_t)m.K * m.n_out : m.n_in);
 }
 
+// spconv_wgrad_x3.hip: weight gradients of the 3^3 / stride-1 convolutions, output-tile stationary on the bf16 matrix cores
+bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int cin, int cout, int64_t in_ld, int64_t gout_ld);
+size_t wgrad_x3t_workspace(int64_t n_rows, int cin, int cout);
+int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gout_ld, int64_t n_rows, int cin, int cout,
+                  const pcmi_kmap_t* map, float* gweight, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
 size_t sort_rows_temp_bytes(int64_t n);
 int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, uint32_t* mask_in, uint32_t* mask_out,
                       int32_t* iota, void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st);

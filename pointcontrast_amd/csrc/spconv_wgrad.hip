@@ -708,7 +708,9 @@ size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, in
   if (M <= 0) M = std::max(n_in, n_out);
   const int lo = wgrad_lo_chunk(n_in, n_out, K, M);
   const int64_t nchunks = K > 1 ? (int64_t)K * ceil_div(wgrad_offset_bound(n_in, n_out), lo) : ceil_div(M, lo);
-  return (size_t)std::max<int64_t>(nchunks, 1) * cin * cout * sizeof(float) + (size_t)1024 * cout * sizeof(float);
+  const size_t pairwise = (size_t)std::max<int64_t>(nchunks, 1) * cin * cout * sizeof(float);
+  const size_t tiled = (K == 27 && n_in == n_out) ? wgrad_x3t_workspace(n_out, cin, cout) : 0;  // spconv_wgrad_x3.hip
+  return std::max(pairwise, tiled) + (size_t)1024 * cout * sizeof(float);
 }
 
 }  // namespace pcmi
@@ -749,6 +751,9 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
     }
     return PCMI_OK;
   }
+  if (!transpose && !gbias && wgrad_x3t_eligible(map, n_in, n_out, cin, cout, in_ld, gout_ld) && in_ld % 4 == 0 &&
+      gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0)
+    return wgrad_x3t_run(in, in_ld, gout, gout_ld, n_out, cin, cout, map, gweight, accumulate, ws, ws_bytes, st);
   WgradArgs a;
   a.x = in;
   a.x_ld = in_ld;

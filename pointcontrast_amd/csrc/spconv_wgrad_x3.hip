@@ -1,0 +1,287 @@
+// Weight gradients of the 3^3 / stride-1 convolutions on the BF16 matrix cores, output-tile stationary:
+//     gW[k][c][n] = sum over the output rows j with a neighbour at offset k of  X[nbr[k][j]][c] * G[j][n]
+//
+// Why a second kernel.  wgrad_mfma_kernel (spconv_wgrad.hip) walks the pair list of ONE offset per workgroup with the
+// fp32 MFMA instruction and reads both operand rows of every pair from global memory: a row is fetched once per offset
+// it occurs in (~17 times; PMC: 2.25 GB per level-1 launch at 4.4 TB/s for 134 MB of unique data), and the fp32
+// instruction runs at 1/16 of the bf16 rate.  Here
+//   * a workgroup owns a range of output rows (in the map's mask-sorted processing order) and a GROUP of KG offsets whose
+//     accumulators it keeps in registers over its whole row range: the G rows of a 64-row tile are staged ONCE per tile
+//     and group, the X rows are gathered per (tile, occupied offset) -- absent offsets of a tile are skipped;
+//   * both operands go through LDS as three bf16 terms each (x = h + m + l exactly, x3_split.h) in a "contraction-packed"
+//     layout: one 16-byte cell = the 8 consecutive tile rows of ONE channel, so that the fragment lane (i, kk) of
+//     v_mfma_f32_16x16x32_bf16 needs -- A[i][8 kk .. 8 kk + 7] = 8 rows of channel i -- is ONE ds_read_b128.  The
+//     transposition (memory is row-major, the contraction runs over rows) happens in registers for free: a staging
+//     lane gathers the float4 of 8 rows and then holds 8 rows x 4 channels;
+//   * cells sit at [term][row group rg][channel ^ rg]: the XOR makes the 8 lanes of a ds_write_b128 service group (8 row
+//     groups, same channel) and the 16 lanes of a ds_read_b128 service group (MI355X_MICROARCH.md, LDS) hit distinct
+//     16-byte slots -- both conflict-free;
+//   * six bf16 MFMAs per fp32-equivalent tile, small terms first (as spconv16x_kernel); fp32 accumulation.
+// The row-block partial sums leave as slabs [k][row block][cin][cout] and are added in row-block order by
+// wgrad_slab_sum_kernel (deterministic, no float atomics).  Two workgroups per CU (<= 80 KB of LDS, <= 256 registers):
+// one stages while the other multiplies.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "internal.h"
+#include "x3_split.h"
+
+namespace pcmi {
+
+struct WgradTArgs {
+  const float* x;       // [*, x_ld] convolution input (rows addressed by the table)
+  int64_t x_ld;
+  const float* g;       // [*, g_ld] gradient of the convolution output
+  int64_t g_ld;
+  const int32_t* nbr;   // [K][n_rows] neighbour table in processing order (nbr_perm when perm is set)
+  const int32_t* perm;  // nullable: position -> output row
+  int64_t n_rows;
+  int K, C, N;
+  int RB, NG;           // row blocks (multiple of 8), offset groups
+  int tiles_per_rb;     // 64-row tiles per row block
+  float* slabs;         // [K][RB][C][N]
+};
+
+template <int MTW, int NTW, int KG>
+__global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
+  constexpr int TR = 64, RG = TR / 8;          // rows per tile, groups of 8 rows
+  constexpr int CB = 32 * MTW, NB = 32 * NTW;  // channel block of the workgroup: 2 waves x MTW (NTW) tiles of 16
+  constexpr uint32_t kAbsent = 0x80000000u;
+  constexpr int kRsrcFlags = 0x00020000;       // raw buffer, 32-bit data format
+  __shared__ __attribute__((aligned(16))) u32x4 s_x[3 * RG * CB];
+  __shared__ __attribute__((aligned(16))) u32x4 s_g[3 * RG * NB];
+  __shared__ uint32_t s_xoff[KG][TR];
+  __shared__ uint32_t s_goff[TR];
+  __shared__ int s_any[KG];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  // workgroup -> (row block, offset group): the groups of one row block share an XCD (b % 8, observed placement, speed
+  // only) and are dispatched next to each other, so the rows they all read are fetched into that L2 once
+  const int b = blockIdx.x;
+  const int og = (b >> 3) % a.NG;
+  const int rb = (b & 7) + 8 * (b / (8 * a.NG));
+  const int kbase = og * KG;
+  const int c0 = blockIdx.y * CB, n0 = blockIdx.z * NB;
+  const int n_tiles = (int)((a.n_rows + TR - 1) / TR);
+  const int t0 = rb * a.tiles_per_rb, t1 = min(t0 + a.tiles_per_rb, n_tiles);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7FFFFFFF, kRsrcFlags);
+  const uint32_t xld = (uint32_t)(a.x_ld * 4), gld = (uint32_t)(a.g_ld * 4);
+
+  f32x4 acc[KG][MTW][NTW];
+#pragma unroll
+  for (int s = 0; s < KG; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[s][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // staging task of a thread: row group rg (8 consecutive tile rows) x channel quad q -- 8 consecutive lanes take the 8
+  // row groups of one quad (the LDS write pattern the XOR above is made for)
+  const int rg_s = t & 7, q_s = t >> 3;
+  auto stage = [&](u32x4* dst, const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, int width) {
+    if (q_s < width / 4) {
+      v4f v[8];
+      const uint32_t col = (uint32_t)(ch0 + 4 * q_s) * 4u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)  // an absent row has an offset >= 2^31: out of range, the load returns zeros
+        v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offs[8 * rg_s + e] + col, 0, 0));
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const v4f x0 = {v[0][e4], v[1][e4], v[2][e4], v[3][e4]}, x1 = {v[4][e4], v[5][e4], v[6][e4], v[7][e4]};
+        u32x4 h, m, l;
+        split3(x0, x1, h, m, l);
+        const int cell = rg_s * width + ((4 * q_s + e4) ^ rg_s);
+        dst[cell] = h;
+        dst[RG * width + cell] = m;
+        dst[2 * RG * width + cell] = l;
+      }
+    }
+  };
+
+  for (int tile = t0; tile < t1; ++tile) {
+    const int64_t p0 = (int64_t)tile * TR;
+    __syncthreads();  // the previous tile's products are done with the offsets and the staged operands
+    if (t < TR) {
+      const int64_t pos = p0 + t;
+      uint32_t o = kAbsent;
+      if (pos < a.n_rows) o = (uint32_t)(a.perm ? a.perm[pos] : (int32_t)pos) * gld;
+      s_goff[t] = o;
+    }
+    for (int idx = t; idx < KG * TR; idx += 256) {  // a wave handles the 64 rows of one offset per round
+      const int s = idx >> 6, rr = idx & 63, k = kbase + s;
+      const int64_t pos = p0 + rr;
+      int32_t v = -1;
+      if (k < a.K && pos < a.n_rows) v = a.nbr[(int64_t)k * a.n_rows + pos];
+      s_xoff[s][rr] = v >= 0 ? (uint32_t)v * xld : kAbsent;
+      const bool any = __ballot(v >= 0) != 0ull;
+      if (lane == 0) s_any[s] = any ? 1 : 0;
+    }
+    __syncthreads();
+    bool any_k = false;
+#pragma unroll
+    for (int s = 0; s < KG; ++s) any_k |= s_any[s] != 0;
+    if (!any_k) continue;  // (uniform) no offset of this group occurs in the tile
+    stage(s_g, gr, s_goff, n0, NB);
+#pragma unroll
+    for (int s = 0; s < KG; ++s) {
+      if (s_any[s] == 0) continue;  // (uniform)
+      stage(s_x, xr, s_xoff[s], c0, CB);
+      __syncthreads();
+#pragma unroll
+      for (int step = 0; step < TR / 32; ++step) {
+        const int rgq = 4 * step + kk;  // the 8 rows this lane quad contracts in this MFMA
+        u32x4 ah[MTW], am[MTW], al[MTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int cell = rgq * CB + ((16 * (wm * MTW + mt) + i) ^ rgq);
+          ah[mt] = s_x[cell];
+          am[mt] = s_x[RG * CB + cell];
+          al[mt] = s_x[2 * RG * CB + cell];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int cell = rgq * NB + ((16 * (wn * NTW + nt) + i) ^ rgq);
+          const u32x4 bh = s_g[cell], bm = s_g[RG * NB + cell], bl = s_g[2 * RG * NB + cell];
+#define PCMI_WX3_MFMA(AT, BT)                                                                                              \
+  acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[mt]), __builtin_bit_cast(bf16x8, BT), \
+                                                           acc[s][mt][nt], 0, 0, 0)
+          // six products per tile, the small ones first; the MTW tiles of a term alternate (independent accumulators)
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(al, bh);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bl);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(am, bm);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(am, bh);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bm);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bh);
+#undef PCMI_WX3_MFMA
+        }
+      }
+      __syncthreads();  // s_x is restaged for the next offset (s_g / the offsets for the next tile)
+    }
+  }
+
+  // ---- slabs: D[row = 4 kk + r][col = i] of every 16x16 tile; row = input channel, col = output channel ------------
+#pragma unroll
+  for (int s = 0; s < KG; ++s) {
+    const int k = kbase + s;
+    if (k >= a.K) continue;
+    float* slab = a.slabs + ((int64_t)k * a.RB + rb) * a.C * a.N;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = c0 + 16 * (wm * MTW + mt) + 4 * kk + r, n = n0 + 16 * (wn * NTW + nt) + i;
+          slab[(int64_t)c * a.N + n] = acc[s][mt][nt][r];
+        }
+  }
+}
+
+// gW[k][e] (+)= sum over the row blocks of slab[k][rb][e], in row-block order.  32 elements x 8 row-block lanes per
+// workgroup, folded through LDS (the chain of dependent loads is RB / 8 long).
+__global__ __launch_bounds__(256) void wgrad_slab_sum_kernel(const float* __restrict__ slabs, int RB, int64_t per_k,
+                                                             float* __restrict__ gw, int accumulate) {
+  __shared__ float s_part[8][33];
+  const int k = blockIdx.y;
+  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (e < per_k)
+    for (int r = cl; r < RB; r += 8) s += slabs[((int64_t)k * RB + r) * per_k + e];
+  s_part[cl][el] = s;
+  __syncthreads();
+  if (cl != 0 || e >= per_k) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += s_part[q][el];
+  float* dst = gw + (int64_t)k * per_k + e;
+  *dst = accumulate ? *dst + s : s;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+constexpr int kWgradTKG = 4;     // offsets whose accumulators a workgroup holds
+constexpr int kWgradTMaxRB = 128;
+
+static int wgrad_x3t_tw(int c) { return c % 96 == 0 ? 3 : (c % 64 == 0 ? 2 : 0); }  // 16-wide tiles per wave and axis
+
+// PCMI_WGRAD_X3T: minimum number of rows for the tile-stationary split-precision kernel (0 = never).  Read per call:
+// the parity test runs both kernels in one process.
+static int64_t wgrad_x3t_min_rows() {
+  const char* e = getenv("PCMI_WGRAD_X3T");
+  return e ? (int64_t)atoll(e) : (int64_t)8192;
+}
+
+bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int cin, int cout, int64_t in_ld, int64_t gout_ld) {
+  const int64_t mr = wgrad_x3t_min_rows();
+  return map && map->kernel_size == 3 && map->stride == 1 && mr > 0 && n_out >= mr && n_in == n_out && cin >= 64 && cout >= 64 &&
+         wgrad_x3t_tw(cin) > 0 && wgrad_x3t_tw(cout) > 0 && n_in * in_ld * 4 <= 0x7FFFFF00ll && n_out * gout_ld * 4 <= 0x7FFFFF00ll;
+}
+
+static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz) {
+  const int NG = (PCMI_MAX_KERNEL_VOLUME + kWgradTKG - 1) / kWgradTKG;
+  const int64_t n_tiles = ceil_div(n_rows, 64);
+  // two resident workgroups per CU; one round of them, at least 4 tiles per workgroup, a multiple of 8 row blocks
+  int64_t rb = (int64_t)2 * num_cu() / ((int64_t)NG * gy * gz);
+  rb = std::min<int64_t>(rb, n_tiles / 4);
+  rb = std::max<int64_t>(8, std::min<int64_t>(kWgradTMaxRB, rb / 8 * 8));
+  return (int)rb;
+}
+
+size_t wgrad_x3t_workspace(int64_t n_rows, int cin, int cout) {
+  const int MTW = wgrad_x3t_tw(cin), NTW = wgrad_x3t_tw(cout);
+  const int64_t mr = wgrad_x3t_min_rows();
+  if (MTW == 0 || NTW == 0 || mr <= 0 || n_rows < mr || cin < 64 || cout < 64) return 0;
+  return (size_t)PCMI_MAX_KERNEL_VOLUME * wgrad_x3t_rb(n_rows, cin / (32 * MTW), cout / (32 * NTW)) * cin * cout * sizeof(float);
+}
+
+template <int MTW, int NTW>
+static void launch_x3t(const WgradTArgs& a, dim3 grid, hipStream_t st) {
+  wgrad_x3t_kernel<MTW, NTW, kWgradTKG><<<grid, 256, 0, st>>>(a);
+}
+
+int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gout_ld, int64_t n_rows, int cin, int cout,
+                  const pcmi_kmap_t* map, float* gweight, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int MTW = wgrad_x3t_tw(cin), NTW = wgrad_x3t_tw(cout);
+  PCMI_REQUIRE(MTW > 0 && NTW > 0 && map && map->K <= PCMI_MAX_KERNEL_VOLUME, PCMI_ERR_UNSUPPORTED, "wgrad x3t: channels (%d, %d)", cin, cout);
+  WgradTArgs a;
+  a.x = in;
+  a.x_ld = in_ld;
+  a.g = gout;
+  a.g_ld = gout_ld;
+  a.nbr = (map->perm && map->nbr_perm) ? map->nbr_perm : map->nbr;
+  a.perm = (map->perm && map->nbr_perm) ? map->perm : nullptr;
+  a.n_rows = n_rows;
+  a.K = map->K;
+  a.C = cin;
+  a.N = cout;
+  const int gy = cin / (32 * MTW), gz = cout / (32 * NTW);
+  a.NG = (map->K + kWgradTKG - 1) / kWgradTKG;
+  a.RB = wgrad_x3t_rb(n_rows, gy, gz);
+  a.tiles_per_rb = (int)ceil_div(ceil_div(n_rows, 64), a.RB);
+  const size_t need = (size_t)map->K * a.RB * cin * cout * sizeof(float);
+  PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "wgrad x3t: workspace %zu < %zu bytes", ws_bytes, need);
+  a.slabs = (float*)ws;
+  const dim3 grid((unsigned)(a.RB * a.NG), (unsigned)gy, (unsigned)gz);
+  switch (MTW * 4 + NTW) {
+    case 3 * 4 + 3: launch_x3t<3, 3>(a, grid, st); break;
+    case 3 * 4 + 2: launch_x3t<3, 2>(a, grid, st); break;
+    case 2 * 4 + 3: launch_x3t<2, 3>(a, grid, st); break;
+    default: launch_x3t<2, 2>(a, grid, st); break;
+  }
+  PCMI_LAUNCH_CHECK();
+  const int64_t per_k = (int64_t)cin * cout;
+  wgrad_slab_sum_kernel<<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)map->K), 256, 0, st>>>(a.slabs, a.RB, per_k, gweight, accumulate);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+}  // namespace pcmi

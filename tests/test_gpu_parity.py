@@ -1104,6 +1104,49 @@ def test_conv16_x3_split_precision_matches_fp32(ME, size, cin, cout, dma, monkey
       json.dump(report, f)
 
 
+@pytest.mark.parametrize("size,cin,cout", [("mid", 64, 64), ("mid", 96, 96), ("large", 96, 96), ("large", 128, 96),
+                                           ("large", 64, 128), ("large", 192, 128)])
+def test_wgrad_x3t_split_precision_matches_fp64(ME, size, cin, cout, monkeypatch):
+  """wgrad_x3t_kernel (csrc/spconv_wgrad_x3.hip: output-tile stationary, both operands as three bf16 terms through
+  contraction-packed LDS cells, six v_mfma_f32_16x16x32_bf16 per tile) against the pair-list fp32-MFMA kernel
+  (PCMI_WGRAD_X3T=0) and against a float64 contraction, on operands with a wide dynamic range.  The split form must be
+  as close to float64 as the fp32 kernel is; an offset WITHOUT pairs (its rows removed from the table) must come out
+  exactly zero."""
+  import json
+  from pointcontrast_amd import functional as PF
+  C = _coords(size)
+  assert len(C) >= 8192
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  m = cm.kernel_map(key, key, 3, 1, 3)
+  torch.manual_seed(8)
+  W = (torch.randn(27, cin, cout, device=DEV) / (cin * 27) ** 0.5)
+  g = torch.randn(len(C), cout, device=DEV) * torch.exp(0.5 * torch.randn(len(C), 1, device=DEV))
+  x = torch.randn(len(C), cin, device=DEV) * torch.exp(torch.randn(len(C), 1, device=DEV))
+  nbr = cm.export_map(m)[0].long()
+  g64 = torch.zeros(27, cin, cout, dtype=torch.float64, device=DEV)
+  for k in range(27):
+    ok = nbr[k] >= 0
+    g64[k] = x[nbr[k][ok]].double().t() @ g[ok].double()
+  res = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("PCMI_WGRAD_X3T", mode)
+    Wm = W.clone().requires_grad_(True)
+    y = PF.SparseConvFunction.apply(x, Wm, None, m, False, len(C), cm)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res[mode] = Wm.grad.clone()
+  e = {"fp32": rel_err(res["0"], g64), "x3t": rel_err(res["1"], g64), "x3t_vs_fp32": rel_err(res["1"], res["0"])}
+  what = "%s %d->%d: %s" % (size, cin, cout, json.dumps({k: "%.2e" % v for k, v in e.items()}))
+  print("wgrad errors vs float64:", what)
+  assert not torch.equal(res["0"], res["1"]), "PCMI_WGRAD_X3T did not switch kernels"
+  assert e["fp32"] <= 1e-5, "fp32 kernel vs float64: " + what
+  assert e["x3t"] <= max(4 * e["fp32"], 2e-6), "tile-stationary split-precision kernel vs float64: " + what
+  # per offset: every slice on its own scale (a small slice must not hide behind the largest one)
+  for k in range(27):
+    assert rel_err(res["1"][k], g64[k]) <= 1e-5, "offset %d: %s" % (k, what)
+
+
 def test_engine_prepacked_weights_are_bit_identical(ME, monkeypatch):
   """The native executor packs the weights of every split-precision layer in ONE launch at the top of a forward pass
   (engine.hip: x3_prepack; both orientations, read by the forward and the backward-data launches of that iteration)
