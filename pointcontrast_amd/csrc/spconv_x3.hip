@@ -15,9 +15,9 @@
 // skipping, byte-offset neighbour table, raw buffer loads issued from inside the MFMA stream, unit-balanced launch)
 // with the inner product replaced:
 //   * weights: x3_pack_kernel splits them ONCE per launch into the kernel's LDS image -- per (slice k, 32-channel chunk,
-//     NS-wide output slice) a block [term h|m|l][column n][lane quad kk][8 bf16] -- so staging a chunk is a linear
-//     16-byte copy and a B fragment (8 bf16 = the 8 channels lane (j, kk) contracts) is ONE conflict-free ds_read_b128
-//     (a wave reads 1 KiB contiguous);
+//     NS-wide output slice) a block [term h|m|l][16-column tile][lane quad kk][column][8 bf16] -- so staging a chunk is a
+//     linear 16-byte copy and a B fragment (8 bf16 = the 8 channels lane (j, kk) contracts) is ONE ds_read_b128, conflict-
+//     free by the service groups of that instruction (x3_piece);
 //   * gathered rows: fp32 in memory as before (same HBM / L2 traffic); the 8 floats a lane holds per group and chunk are
 //     split in registers (v_cvt_pk_bf16_f32, 5.5 VALU operations per element, issued beside the other waves' MFMAs);
 //   * v_mfma_f32_16x16x32_bf16: lane (i = l & 15, kk = l >> 4) supplies A[i][8 kk .. 8 kk + 7] and B[8 kk ..][j = i];
@@ -36,6 +36,13 @@
 #include "x3_split.h"
 
 namespace pcmi {
+
+// 16-byte piece of column n (of the NS-wide output slice) and lane quad kk inside one term of a weight block:
+// [16-column tile][kk][column in the tile].  The fragment read of lane (i, kk) for column tile ct is then piece
+// 64 ct + 16 kk + i: the 16 lanes of every ds_read_b128 service group ({0-3, 12-15, 20-27}, ... -- MI355X_MICROARCH.md,
+// LDS) cover 16 different 16-byte slots.  (Round 2's order [column][kk] put lanes i and i + 4 of a quad on the same
+// slot: every fragment read was a 2-way bank conflict.)
+__host__ __device__ constexpr int x3_piece(int n, int kk) { return (n >> 4) * 64 + kk * 16 + (n & 15); }
 
 // channel of chunk-local element e of lane quad kk (see the header)
 __host__ __device__ constexpr int x3_channel(int kk, int e) { return 4 * kk + (e & 3) + 16 * (e >> 2); }
@@ -65,9 +72,10 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
   u32x4 h, m, l;
   split3(x0, x1, h, m, l);
   u32x4* blk = out + (((int64_t)wk * nch + cc) * nns + ns) * (3 * NS * 4);
-  blk[(0 * NS + nl) * 4 + kk] = h;
-  blk[(1 * NS + nl) * 4 + kk] = m;
-  blk[(2 * NS + nl) * 4 + kk] = l;
+  const int piece = x3_piece(nl, kk);
+  blk[0 * NS * 4 + piece] = h;
+  blk[1 * NS * 4 + piece] = m;
+  blk[2 * NS * 4 + piece] = l;
 }
 
 // DMA: the weight block of the next step goes global -> LDS directly (buffer_load_dwordx4 ... lds: the block is a
@@ -103,9 +111,10 @@ __global__ __launch_bounds__(256) void x3_pack_many_kernel(const X3PackJob* __re
   u32x4 h, m, l;
   split3(x0, x1, h, m, l);
   u32x4* blk = reinterpret_cast<u32x4*>(jb.out) + (((int64_t)wk * nch + cc) * nns + ns) * (3 * jb.NS * 4);
-  blk[(0 * jb.NS + nl) * 4 + kk] = h;
-  blk[(1 * jb.NS + nl) * 4 + kk] = m;
-  blk[(2 * jb.NS + nl) * 4 + kk] = l;
+  const int piece = x3_piece(nl, kk);
+  blk[0 * jb.NS * 4 + piece] = h;
+  blk[1 * jb.NS * 4 + piece] = m;
+  blk[2 * jb.NS * 4 + piece] = l;
 }
 
 template <int NT, bool SK, bool DMA>
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
       if (g0) split3(cur[0][0], cur[0][1], ah[0], am[0], al[0]);
       if (g1) split3(cur[1][0], cur[1][1], ah[1], am[1], al[1]);
       // B fragments of column tile ct: piece (term, n = 16 ct + i, kk); a two-tile register ring, read one tile ahead
-      const u32x4* sb = &s_b[step & 1][i * 4 + kk];
+      const u32x4* sb = &s_b[step & 1][kk * 16 + i];  // x3_piece(16 ct + i, kk) = 64 ct + this
       u32x4 bh[2], bm[2], bl[2];
       if (va_cur) {
         bh[0] = sb[0 * NS * 4];
