@@ -239,6 +239,23 @@ int pcmi_scatter_add_rows(const float* src, int64_t src_ld, const int64_t* idx, 
                           float* dst, int64_t dst_ld, pcmi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Positive-pair selection of the PointInfoNCE step (pc/lib/ddp_trainer.py:400-417; csrc/pairs.hip):
+ *   q_unique, count = pos_pairs[:, 0].unique(return_counts=True); off = floor(uniform * count);
+ *   k_sel = pos_pairs[:, 1][off + exclusive_cumsum(count)]; optional sub-sample [sampled] of both.
+ * pairs: device int32 [n_pairs, 2] sorted by column 0 (the loader's contract, pc/lib/ddp_data_loaders.py:43-48,85-91);
+ * uniform: device fp32 [n_unique] -- the host's torch.rand(n_unique) draws; sampled: nullable device int64 [n_sel] --
+ * the host's np.random.choice(n_unique, npos) (NULL: n_sel == n_unique, every query in order).  Writes q_idx / k_idx
+ * (device int64 [n_sel]: rows of F0 / F1).  The random draws stay on the host so that the reference's generator streams
+ * are consumed identically; for them the host needs n_unique: pcmi_pairs_scan_host, one pass over column 0 of the
+ * HOST copy of the correspondences (*sorted_host == 0: the column is not sorted -- sort before using either call).
+ * ------------------------------------------------------------------------------------------ */
+size_t pcmi_pair_select_workspace_bytes(int64_t n_pairs);
+int pcmi_pair_select(const int32_t* pairs, int64_t n_pairs, int64_t n_unique, const float* uniform,
+                     const int64_t* sampled, int64_t n_sel, int64_t* q_idx, int64_t* k_idx, void* ws,
+                     size_t ws_bytes, pcmi_stream_t stream);
+int pcmi_pairs_scan_host(const int32_t* pairs_host, int64_t n_pairs, int64_t* n_runs_host, int* sorted_host);
+
+/* ------------------------------------------------------------------------------------------
  * PointInfoNCE block -- replaces torch.mm + nn.CrossEntropyLoss
  * (pc/lib/ddp_trainer.py:419-426, pc/lib/criterion.py:13-18):
  *   loss = mean_i( logsumexp_j(q_i.k_j / T) - q_i.k_i / T ),  q, k: [n, c] fp32.

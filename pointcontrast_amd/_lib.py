@@ -121,6 +121,9 @@ PROTOTYPES = {
     "pcmi_softmax_ce_workspace_bytes": (c_sz, [c_i64]),
     "pcmi_softmax_ce_fwd": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, C.c_int, c_vp, c_vp, c_sz, c_vp]),
     "pcmi_softmax_ce_bwd": (C.c_int, [c_vp, c_i64, c_i64, C.c_int, c_vp, C.c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "pcmi_pair_select_workspace_bytes": (C.c_size_t, [c_i64]),
+    "pcmi_pair_select": (C.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, C.c_size_t, c_vp]),
+    "pcmi_pairs_scan_host": (C.c_int, [c_vp, c_i64, C.POINTER(c_i64), C.POINTER(C.c_int)]),
     "pcmi_sgd_step": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "pcmi_sgd_step_dampened": (C.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, C.c_int, c_vp]),
     "pcmi_net_create": (C.c_int, [C.POINTER(NetTensor), C.c_int, C.POINTER(NetOp), C.c_int, C.c_int, C.c_int, C.c_int,

@@ -134,6 +134,7 @@ struct pcmi_net {
   hipStream_t side[2] = {nullptr, nullptr};
   hipStream_t chain1 = nullptr;  // chain stream of pass 1 in pcmi_net_backward_pair
   hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_switch = nullptr;
+  hipEvent_t ev_pack_in = nullptr, ev_pack_done = nullptr;  // the weight pack of a forward pass on side[1] (x3_prepack)
   pcmi::DevBuf ws_side[2];
   pcmi::DevBuf grads_peer;
   // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
@@ -153,6 +154,8 @@ struct pcmi_net {
       if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
     }
     if (chain1) (void)hipStreamDestroy(chain1);
+    if (ev_pack_in) (void)hipEventDestroy(ev_pack_in);
+    if (ev_pack_done) (void)hipEventDestroy(ev_pack_done);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_switch) (void)hipEventDestroy(ev_switch);
   }
@@ -330,6 +333,8 @@ static int ensure_streams(pcmi_net& n) {
   }
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_switch, hipEventDisableTiming));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_pack_in, hipEventDisableTiming));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_pack_done, hipEventDisableTiming));
   return PCMI_OK;
 }
 
@@ -788,7 +793,27 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.out_feats = out_feats;
   ps.out_ld = out_ld;
   ps.coords = coords;
-  rc = x3_prepack(n, params, st);
+  // The weight pack (0.2 ms for Res16UNet34C) leaves the chain: pass 0 packs on the executor's second side stream, behind
+  // whatever `st` holds now (the optimiser step that produced these weights), and `st` waits for it in front of the first
+  // convolution that can use a pack -- by then the stem and the 32-channel layers have run.  PCMI_X3_PACK_ASYNC=0 / other
+  // passes: packed in line.
+  static const bool pack_async_on = [] {
+    const char* e = getenv("PCMI_X3_PACK_ASYNC");
+    return !(e && e[0] == '0');
+  }();
+  bool pack_pending = false;
+  if (pack_async_on && pass == 0) {
+    rc = ensure_streams(n);
+    if (rc) return rc;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_pack_in, st));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[1], n.ev_pack_in, 0));
+    rc = x3_prepack(n, params, n.side[1]);
+    if (rc) return rc;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_pack_done, n.side[1]));
+    pack_pending = n.x3_current;
+  } else {
+    rc = x3_prepack(n, params, st);
+  }
   const X3TableScope x3_scope;  // the table is this thread's only until the pass has been enqueued
   if (rc) return rc;
   g_prof_fwd.lap(2);
@@ -798,6 +823,10 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
     if (op.type == PCMI_OP_CONV) {
+      if (pack_pending && op.kernel_size > 1 && op.cin >= 64 && op.cout >= 64) {
+        PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_pack_done, 0));
+        pack_pending = false;
+      }
       rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
                           op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, ps.ws.p, ps.ws.cap,
                           st);
@@ -848,6 +877,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     if (rc) return rc;
     g_prof_fwd.lap(op.type == PCMI_OP_CONV ? 3 : (op.type == PCMI_OP_BN ? 4 : 5));
   }
+  if (pack_pending) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_pack_done, 0));  // (no layer used a pack: the backward pass may)
   if ((defer || two_seg) && ps.upd_n > 0) {
     PCMI_HIP_CHECK(hipMemcpyAsync(ps.upd_dev, ps.upd_host, sizeof(BnRunningUpdate) * ps.upd_n, hipMemcpyHostToDevice, st));
     PCMI_HIP_CHECK(hipEventRecord(ps.upd_copied, st));

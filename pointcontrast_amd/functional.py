@@ -343,6 +343,31 @@ class SoftmaxCrossEntropyFunction(Function):
     return dx, None, None
 
 
+def pairs_scan_host(pos_pairs):
+  """(number of runs of column 0, sorted?) of HOST correspondences [P, 2] int32 -- one native pass (pcmi_pairs_scan_host)."""
+  assert (not pos_pairs.is_cuda) and pos_pairs.dtype == torch.int32 and pos_pairs.dim() == 2 and pos_pairs.shape[1] == 2 \
+      and pos_pairs.is_contiguous(), "correspondences must be a contiguous CPU int32 [P, 2] tensor"
+  n, srt = C.c_int64(), C.c_int()
+  check(lib.pcmi_pairs_scan_host(C.c_void_p(pos_pairs.data_ptr()), pos_pairs.shape[0], C.byref(n), C.byref(srt)))
+  return n.value, bool(srt.value)
+
+
+def pair_select(pairs_dev, n_unique, uniform_dev, sampled_dev=None):
+  """Device side of the PointInfoNCE pair selection (pc/lib/ddp_trainer.py:400-417; pcmi_pair_select): row indices
+  (q_idx into F0, k_idx into F1), int64 [npos] (or [n_unique] without a sub-sample)."""
+  require_cuda(pairs_dev, "pair selection")
+  assert pairs_dev.dtype == torch.int32 and pairs_dev.is_contiguous() and uniform_dev.dtype == torch.float32
+  assert uniform_dev.numel() == n_unique and (sampled_dev is None or sampled_dev.dtype == torch.int64)
+  n_sel = sampled_dev.numel() if sampled_dev is not None else n_unique
+  q = torch.empty(n_sel, dtype=torch.int64, device=pairs_dev.device)
+  k = torch.empty(n_sel, dtype=torch.int64, device=pairs_dev.device)
+  P = pairs_dev.shape[0]
+  ws, wsb = ws_args(lib.pcmi_pair_select_workspace_bytes(P), pairs_dev.device)
+  check(lib.pcmi_pair_select(ptr(pairs_dev), P, n_unique, ptr(uniform_dev), ptr(sampled_dev), n_sel, ptr(q), ptr(k), ws, wsb,
+                             cur_stream(pairs_dev.device)))
+  return q, k
+
+
 def sgd_step(w, g, v, lr, momentum, weight_decay, grad_scale=1.0, dampening=0.0, first_step=True):
   """torch.optim.SGD.step on flat buffers (pc/lib/ddp_trainer.py:107-111,319,435; with dampening:
   downstream/semseg/lib/solvers.py:52-60).  first_step: torch fills a fresh momentum buffer with the gradient itself."""

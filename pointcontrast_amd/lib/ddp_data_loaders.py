@@ -170,14 +170,22 @@ def make_data_loader(config, batch_size, num_threads=0):
   # raises StopIteration after one epoch).
   sampler = DistributedInfSampler(dset) if config.misc.num_gpus > 1 else InfSampler(dset, shuffle=True)
   return torch.utils.data.DataLoader(dset, batch_size=batch_size, shuffle=False, num_workers=num_threads,
-                                     collate_fn=default_collate_pair_fn, pin_memory=False, sampler=sampler, drop_last=True)
+                                     collate_fn=default_collate_pair_fn, pin_memory=torch.cuda.is_available(), sampler=sampler,
+                                     drop_last=True)
 
 
 class FixedBatchLoader:
   """Replays pre-generated batches forever (benchmarks / tests: inputs staged before timing)."""
 
-  def __init__(self, batches, batch_size):
+  def __init__(self, batches, batch_size, pin_memory=None):
     self.batches, self.batch_size = list(batches), batch_size
+    # the staged batches in pinned host memory (what DataLoader(pin_memory=True) hands out): uploads are then truly
+    # asynchronous copies without a pass through a staging buffer
+    if pin_memory is None:
+      pin_memory = torch.cuda.is_available()
+    if pin_memory:
+      self.batches = [{k: (v.pin_memory() if torch.is_tensor(v) and not v.is_cuda and not v.is_pinned() else v) for k, v in b.items()}
+                      for b in self.batches]
 
   def __len__(self):
     return len(self.batches)

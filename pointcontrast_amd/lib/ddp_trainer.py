@@ -463,10 +463,58 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
       q_unique, k_sel = q_unique[si], k_sel[si]
     return q_unique, k_sel
 
+  def _upload_any(self, t_cpu, slot):
+    """A small host vector of any dtype -> device through a persistent pinned staging buffer (see _upload)."""
+    st = getattr(self, "_staging_any", None)
+    if st is None:
+      st = self._staging_any = {}
+    n = t_cpu.numel()
+    buf, ev = st.get(slot, (None, None))
+    if buf is None or buf.numel() < n or buf.dtype != t_cpu.dtype:
+      buf, ev = torch.empty(max(n, 8192), dtype=t_cpu.dtype).pin_memory(), None
+    if ev is not None:
+      ev.synchronize()
+    buf[:n].copy_(t_cpu.reshape(-1))
+    out = buf[:n].to(self.cur_device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st[slot] = (buf, ev)
+    return out
+
+  def select_pairs_device(self, pos_pairs, npos, draws=None, slot=0):
+    """select_pairs with the run detection and the gathers on the device (csrc/pairs.hip): the host keeps what consumes
+    the random-number streams -- torch.rand(n_unique), np.random.choice(n_unique, npos) -- in the same order as
+    select_pairs, plus one native pass over column 0 for n_unique.  Returns device int64 (q_idx, k_idx); bit-identical
+    to select_pairs (tests/test_gpu_parity.py::test_device_pair_selection_is_bit_identical).  None: the correspondences
+    are not a sorted contiguous int32 tensor (the caller falls back to the host path)."""
+    pp = pos_pairs if torch.is_tensor(pos_pairs) else torch.from_numpy(np.asarray(pos_pairs))
+    if pp.is_cuda or pp.dtype != torch.int32 or pp.dim() != 2 or not pp.is_contiguous() or pp.shape[0] == 0:
+      return None
+    nq, is_sorted = PF.pairs_scan_host(pp)
+    if not is_sorted:
+      return None
+    draws = draws or {}
+    uniform = draws["uniform"] if "uniform" in draws else torch.rand(nq)
+    uniform = torch.as_tensor(uniform, dtype=torch.float32)
+    assert uniform.numel() == nq, "uniform draws: %d for %d unique queries" % (uniform.numel(), nq)
+    si = None
+    if npos < nq:
+      si = draws["sampled_inds"] if "sampled_inds" in draws else np.random.choice(nq, npos, replace=False)
+      si = torch.as_tensor(np.asarray(si)).long()
+    pairs_d = pp.to(self.cur_device, non_blocking=True) if pp.is_pinned() else self._upload_any(pp, ("pairs", slot)).view(pp.shape)
+    u_d = self._upload_any(uniform, ("uniform", slot))
+    si_d = self._upload_any(si, ("sampled", slot)) if si is not None else None
+    return PF.pair_select(pairs_d, nq, u_d, si_d)
+
   def _prepare_loss(self, prep, draws):
-    q_idx, k_idx = self.select_pairs(prep["input"]["correspondences"], self.npos, draws)
     slot = getattr(self, "_slot", 0)
     self._slot = slot ^ 2  # two staging buffer pairs: the prefetched batch must not overwrite the live one
+    if self.config.misc.get("device_pair_selection", True):
+      sel = self.select_pairs_device(prep["input"]["correspondences"], self.npos, draws, slot)
+      if sel is not None:
+        prep["q_idx"], prep["k_idx"] = sel
+        return
+    q_idx, k_idx = self.select_pairs(prep["input"]["correspondences"], self.npos, draws)
     prep["q_idx"], prep["k_idx"] = self._upload(q_idx, slot), self._upload(k_idx, slot + 1)
 
   def _train_iter(self, data_loader_iter, timers, draws=None):

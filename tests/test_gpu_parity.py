@@ -404,6 +404,44 @@ def test_nce_parity(n, T):
   assert_close(kd.grad, kr.grad, 2e-4, "nce dk")
 
 
+@pytest.mark.parametrize("n_queries,npos", [(70000, 4096), (3000, 4096), (1, 4096)])
+def test_device_pair_selection_is_bit_identical(n_queries, npos):
+  """csrc/pairs.hip (run starts of the sorted query column, floor(uniform * count) pick, npos sub-sample on the device; the
+  random draws on the host) against the host-side select_pairs and the oracle's restatement of
+  pc/lib/ddp_trainer.py:400-417 -- with injected draws and with the global generators (same stream consumption)."""
+  import types
+  from oracle import loss_ref as lr
+  from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
+  rng = np.random.RandomState(n_queries)
+  counts = rng.randint(1, 30, n_queries)
+  q = np.repeat(np.sort(rng.choice(10 * n_queries, n_queries, replace=False)), counts).astype(np.int32)
+  pp = torch.from_numpy(np.stack([q, rng.randint(0, 10 * n_queries, len(q)).astype(np.int32)], 1).copy())
+  tr = PointNCELossTrainer.__new__(PointNCELossTrainer)
+  tr.cur_device = torch.device(DEV)
+  draws = dict(uniform=torch.rand(n_queries, generator=torch.Generator().manual_seed(3)))
+  if npos < n_queries:
+    draws["sampled_inds"] = np.random.RandomState(3).choice(n_queries, npos, replace=False)
+  qd, kd = tr.select_pairs_device(pp, npos, draws)
+  qh, kh = PointNCELossTrainer.select_pairs(pp, npos, draws)
+  qr, kr = lr.nce_select_pairs(pp.numpy(), draws["uniform"], draws.get("sampled_inds"))
+  assert torch.equal(qd.cpu(), qh) and torch.equal(kd.cpu(), kh) and torch.equal(qh, qr) and torch.equal(kh, kr)
+  # the global generators: both paths consume torch's and numpy's streams identically
+  torch.manual_seed(9)
+  np.random.seed(9)
+  qd, kd = tr.select_pairs_device(pp.pin_memory(), npos)
+  a = (torch.rand(1).item(), np.random.rand())
+  torch.manual_seed(9)
+  np.random.seed(9)
+  qh, kh = PointNCELossTrainer.select_pairs(pp, npos)
+  assert (torch.rand(1).item(), np.random.rand()) == a
+  assert torch.equal(qd.cpu(), qh) and torch.equal(kd.cpu(), kh)
+  # unsorted correspondences: the device path declines (the trainer then sorts on the host, as round 2 did)
+  if n_queries > 1:
+    bad = pp.clone()
+    bad[[0, len(pp) - 1]] = bad[[len(pp) - 1, 0]]
+    assert tr.select_pairs_device(bad, npos, draws) is None
+
+
 def test_gather_scatter_rows():
   from pointcontrast_amd import functional as PF
   torch.manual_seed(0)
@@ -1129,8 +1167,9 @@ def test_wgrad_x3t_split_precision_matches_fp64(ME, size, cin, cout, monkeypatch
     ok = nbr[k] >= 0
     g64[k] = x[nbr[k][ok]].double().t() @ g[ok].double()
   res = {}
+  monkeypatch.setenv("PCMI_WGRAD_X3T_MAX", "100000000")
   for mode in ("0", "1"):
-    monkeypatch.setenv("PCMI_WGRAD_X3T", mode)
+    monkeypatch.setenv("PCMI_WGRAD_X3T", mode)  # 0: the pair-list kernel; 1: the tile-stationary kernel at every size
     Wm = W.clone().requires_grad_(True)
     y = PF.SparseConvFunction.apply(x, Wm, None, m, False, len(C), cm)
     y.backward(g)

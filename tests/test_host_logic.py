@@ -401,3 +401,19 @@ def test_samplers_reproduce_the_reference_classes():
       mk = lambda m: m.DistributedInfSampler(data, world, rank, True)
       assert stream(ref, mk) == stream(ds, mk), (world, rank)
       assert len(mk(ref)) == len(mk(ds))
+
+
+def test_pairs_scan_host_counts_runs_and_detects_unsorted_input(built_lib):
+  """pcmi_pairs_scan_host (csrc/pairs.hip, host side of the device pair selection): number of unique queries of a sorted
+  column 0 in one native pass, and the sortedness flag that sends unsorted correspondences to the host path."""
+  import torch
+  from pointcontrast_amd import functional as PF
+  rng = np.random.RandomState(0)
+  for n in (0, 1, 7, 70000, 300001):
+    q = np.sort(rng.randint(0, max(n // 12, 1), n)).astype(np.int32)
+    pp = torch.from_numpy(np.stack([q, rng.randint(0, 1000, n).astype(np.int32)], 1).copy())
+    runs, ok = PF.pairs_scan_host(pp)
+    assert ok and runs == len(np.unique(q)), (n, runs)
+    if n > 10:
+      pp[n // 2, 0] = -1
+      assert PF.pairs_scan_host(pp)[1] is False
