@@ -396,15 +396,6 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
 int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_ld,
                       const float* params, float* grads, const int64_t* bucket_lo_host,
                       int n_buckets, pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream);
-/* The two backwards of an iteration (passes 0 and 1, both forwarded in training mode) next to
- * each other: pass 1 on an internal stream forked from `stream`, pass 0 on `stream`, joined
- * before the call's last enqueued work; `grads` receives exactly what
- * pcmi_net_backward(1) followed by pcmi_net_backward(0) accumulate (same summation order). `ready`
- * fires on a bucket once BOTH passes have contributed to it. */
-int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, const float* d_out1,
-                           int64_t d_ld1, const float* params, float* grads,
-                           const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready,
-                           void* ready_ctx, pcmi_stream_t stream);
 int pcmi_net_apply_running_stats(pcmi_net_t* net, int pass, pcmi_stream_t stream);
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes);
 

@@ -97,13 +97,10 @@ struct PassState {
   DevBuf grad;
   std::vector<size_t> grad_off;
   DevBuf small;  // dgamma / dbeta scratch
-  // pass run as the DEFERRED half of pcmi_net_backward_pair: how far it got at every bucket boundary
-  std::vector<hipEvent_t> bucket_ev;
   ~PassState() {
     if (upd_host) (void)hipHostFree(upd_host);
     if (upd_dev) (void)hipFree(upd_dev);
     if (upd_copied) (void)hipEventDestroy(upd_copied);
-    for (hipEvent_t e : bucket_ev) (void)hipEventDestroy(e);
   }
   std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
   std::vector<size_t> stat_off;    // per op: BN save_mean/save_invstd (2*C floats) or L2 norms
@@ -127,16 +124,12 @@ struct pcmi_net {
   std::vector<pcmi::OpPlan> plan;
   int input_tensor = -1, output_tensor = -1, n_levels = 0;
   std::vector<pcmi::PassState> passes;
-  // backward: the weight gradients (off the critical path: nothing downstream reads them) run on a side stream
-  // next to the bwd-data -> BN-bwd chain, with a workspace of their own.  pcmi_net_backward_pair runs the two passes
-  // of an iteration concurrently: each has its own chain stream, weight-gradient stream and workspace, and pass 1
-  // writes its parameter gradients to `grads_peer` (added to the caller's buffer bucket by bucket by pass 0).
+  // side[0]: the weight gradients of a backward pass (off the critical path: nothing downstream reads them), with a
+  // workspace of their own; side[1]: the weight pack of a forward pass (x3_prepack).  Both at the lowest priority.
   hipStream_t side[2] = {nullptr, nullptr};
-  hipStream_t chain1 = nullptr;  // chain stream of pass 1 in pcmi_net_backward_pair
-  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_fork = nullptr, ev_switch = nullptr;
-  hipEvent_t ev_pack_in = nullptr, ev_pack_done = nullptr;  // the weight pack of a forward pass on side[1] (x3_prepack)
+  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};
+  hipEvent_t ev_pack_in = nullptr, ev_pack_done = nullptr;
   pcmi::DevBuf ws_side[2];
-  pcmi::DevBuf grads_peer;
   // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
   // top of a forward pass (x3_prepack) instead of one pack launch in front of every convolution
   pcmi::DevBuf x3_packs, x3_jobs_dev;
@@ -153,11 +146,8 @@ struct pcmi_net {
       if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
       if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
     }
-    if (chain1) (void)hipStreamDestroy(chain1);
     if (ev_pack_in) (void)hipEventDestroy(ev_pack_in);
     if (ev_pack_done) (void)hipEventDestroy(ev_pack_done);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_switch) (void)hipEventDestroy(ev_switch);
   }
 };
 
@@ -289,59 +279,36 @@ struct X3TableScope {
 };
 
 // ---- backward -----------------------------------------------------------------------------------------
-// One pass's backward is a chain (bwd-data -> BN-bwd -> ...) on a "chain" stream plus the weight gradients,
-// which nothing downstream reads, on a weight-gradient stream.  pcmi_net_backward_pair runs the two passes of an
-// iteration next to each other: pass 1 (DEFERRED) on the executor's second chain stream + second weight-gradient
-// stream, writing its parameter gradients (each parameter belongs to exactly one op, so they are plain stores) to
-// the executor's peer buffer; pass 0 (PRIMARY) on the caller's stream, accumulating into the caller's `grads` as a
-// solo pass does.  When PRIMARY reaches a bucket boundary it waits for DEFERRED to have passed the same boundary,
-// adds the peer buffer's slice and only then declares the bucket final.  (0 + g0) + g1 == (0 + g1) + g0 bit for bit,
-// so the result equals two sequential backwards into a zeroed buffer.
+// One pass's backward is a chain (bwd-data -> BN-bwd -> ...) on the caller's stream plus the weight gradients, which
+// nothing downstream reads, on a low-priority side stream with a workspace of their own.  (Round 2 also carried a
+// two-chain form that ran the backward passes of the two clouds next to each other -- bit-identical, 111 against 174
+// pairs/s, a queueing effect of five concurrently active streams; the pair as ONE two-segment pass replaced it and the
+// code is gone.)
 struct BackwardJob {
-  enum Role { SOLO, DEFERRED, PRIMARY };
   int pass = 0;
   const float* d_out = nullptr;
   int64_t d_ld = 0;
   hipStream_t st = nullptr;
-  Role role = SOLO;
 };
-
-__global__ __launch_bounds__(256) void grads_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    float4 d = reinterpret_cast<float4*>(dst)[i];
-    const float4 v = reinterpret_cast<const float4*>(src)[i];
-    d.x += v.x;
-    d.y += v.y;
-    d.z += v.z;
-    d.w += v.w;
-    reinterpret_cast<float4*>(dst)[i] = d;
-  }
-}
 
 static int ensure_streams(pcmi_net& n) {
   if (n.side[0]) return PCMI_OK;
   // the weight gradients are off the critical path: lowest priority, so that the chain's kernels are dispatched
-  // first and the weight-gradient workgroups fill what they leave idle (PCMI_WGRAD_PRIORITY=0: same priority)
+  // first and the weight-gradient workgroups fill what they leave idle (same priority measured: 17.5-19.4 against
+  // 16.6 ms per iteration; weight gradients on the chain's own stream: 28 ms)
   int least = 0, greatest = 0;
   PCMI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  const char* pe = getenv("PCMI_WGRAD_PRIORITY");
-  const int prio = (pe && pe[0] == '0') ? 0 : least;
-  for (int i = 0; i < 2; ++i) {
-    PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, prio));
+  for (int i = 0; i < 2; ++i) {  // [0]: weight gradients; [1]: the weight pack of a forward pass
+    PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, least));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
   }
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_switch, hipEventDisableTiming));
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_pack_in, hipEventDisableTiming));
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_pack_done, hipEventDisableTiming));
   return PCMI_OK;
 }
 
-// One pass's backward as an object the caller advances op by op: pcmi_net_backward_pair interleaves the ENQUEUE of its
-// two passes (op i of pass 1, op i of pass 0, op i-1 of pass 1, ...), so that both chains are present on the GPU at
-// the same time -- enqueueing one whole pass after the other leaves the second chain ~10 ms of host time behind the
-// first, i.e. no overlap at all.
+// One pass's backward: op by op in reverse, the chain on `st`, the weight gradients on the side stream.
 struct BackwardRun {
   pcmi_net& n;
   BackwardJob job;
@@ -354,12 +321,9 @@ struct BackwardRun {
   // set by begin()
   hipStream_t st = nullptr, wst = nullptr;
   PassState* ps = nullptr;
-  PassState* peer = nullptr;
   DevBuf* wws = nullptr;
   float* scratch_g = nullptr;
-  float* gdst = nullptr;
-  int gacc = 1, sidx = 0;
-  bool deferred = false, primary = false, side_pending = false;
+  bool side_pending = false;
   std::vector<int> bucket_last;
 
   BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
@@ -368,24 +332,9 @@ struct BackwardRun {
 
   int join_side() {  // `st` continues only after the weight gradients enqueued so far
     if (!side_pending) return PCMI_OK;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_side[sidx], wst));
-    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[sidx], 0));
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_side[0], wst));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));
     side_pending = false;
-    return PCMI_OK;
-  }
-  int64_t bucket_hi(int q) const { return q + 1 < n_buckets ? bucket_lo_host[q + 1] : n.param_extent; }
-  // everything the DEFERRED peer contributes to [lo, hi) is added to `grads` (q: the peer's boundary event)
-  int absorb_peer(int q, int64_t lo, int64_t hi) {
-    int r = join_side();
-    if (r) return r;
-    PCMI_HIP_CHECK(hipStreamWaitEvent(st, peer->bucket_ev[q], 0));
-    lo = lo / 4 * 4;
-    const int64_t n4 = (std::min(hi, n.param_extent) - lo + 3) / 4;
-    if (n4 > 0) {
-      const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(n4, 256), 2048);
-      grads_add_kernel<<<blocks, 256, 0, st>>>(grads + lo, (const float*)n.grads_peer.p + lo, n4);
-      PCMI_LAUNCH_CHECK();
-    }
     return PCMI_OK;
   }
   int bucket_of(int64_t offp) const {
@@ -400,7 +349,6 @@ struct BackwardRun {
     ps = &n.passes[job.pass];
     const int n_ops = (int)n.ops.size(), n_t = (int)n.tensors.size();
     if (n_buckets < 0 || !bucket_lo_host) n_buckets = 0;
-    // gradient arena of this pass (its own: the two passes of a pair run concurrently)
     ps->grad_off.assign(n_t, 0);
     size_t off = 0;
     int max_c = 4;
@@ -415,38 +363,12 @@ struct BackwardRun {
     rc = ps->small.reserve((size_t)4 * max_c * sizeof(float) + 256, st);  // per segment: dbeta, dgamma
     if (rc) return rc;
     scratch_g = (float*)ps->small.p;
-    deferred = job.role == BackwardJob::DEFERRED;
-    primary = job.role == BackwardJob::PRIMARY;
-    peer = primary ? &n.passes[1] : nullptr;
-    // where this pass's parameter gradients go: DEFERRED stores into the peer buffer, the others accumulate
-    gdst = deferred ? (float*)n.grads_peer.p : grads;
-    gacc = deferred ? 0 : 1;
-    if (deferred)
-      while ((int)ps->bucket_ev.size() < n_buckets + 1) {
-        hipEvent_t e;
-        PCMI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ps->bucket_ev.push_back(e);
-      }
-    // ---- weight-gradient stream ----------------------------------------------------------------------
-    static const bool side_enabled = [] {
-      const char* e = getenv("PCMI_WGRAD_SIDE_STREAM");
-      return !(e && e[0] == '0');
-    }();
-    static const bool one_side = [] {  // PCMI_PAIR_ONE_SIDE=1: both passes of a pair share weight-gradient stream 0
-      const char* e = getenv("PCMI_PAIR_ONE_SIDE");
-      return e && e[0] == '1';
-    }();
-    sidx = (deferred && !one_side) ? 1 : 0;
-    wst = st;
-    wws = &ps->ws;
-    if (side_enabled || job.role != BackwardJob::SOLO) {
-      rc = ensure_streams(n);
-      if (rc) return rc;
-      rc = n.ws_side[sidx].reserve(ps->ws.cap, n.side[sidx]);
-      if (rc) return rc;
-      wst = n.side[sidx];
-      wws = &n.ws_side[sidx];
-    }
+    rc = ensure_streams(n);
+    if (rc) return rc;
+    rc = n.ws_side[0].reserve(ps->ws.cap, n.side[0]);
+    if (rc) return rc;
+    wst = n.side[0];
+    wws = &n.ws_side[0];
     side_pending = false;
     // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
     bucket_last.assign(n_buckets, -1);
@@ -459,29 +381,10 @@ struct BackwardRun {
     return PCMI_OK;
   }
 
-  // DEFERRED only: ops that touch a level below `own_from` run on `shared` (the PRIMARY pass's stream, i.e. in turn
-  // with its ops), the others on this pass's own chain stream.  Measured: the full-resolution kernels of two passes
-  // side by side cost more than they gain (they each want the whole chip and its L2), the latency-bound kernels of the
-  // coarse levels are the ones that overlap.
-  hipStream_t shared = nullptr, own = nullptr;
-  int own_from = 0;
-  int move_to(hipStream_t target) {
-    if (target == st) return PCMI_OK;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_switch, st));
-    PCMI_HIP_CHECK(hipStreamWaitEvent(target, n.ev_switch, 0));
-    st = target;
-    return PCMI_OK;
-  }
-
   int step(int i) {  // differentiate op i (called for i = n_ops - 1 ... 0)
     const float* d_out = job.d_out;
     const int64_t d_ld = job.d_ld;
     const auto& op = n.ops[i];
-    if (shared) {
-      const int lv = std::min(n.tensors[op.in].level, n.tensors[op.out].level);
-      const int rc0 = move_to(lv < own_from ? shared : own);
-      if (rc0) return rc0;
-    }
     const OpPlan& pl = n.plan[i];
     const View x = act_view(n, *ps, op.in), y = act_view(n, *ps, op.out);
     const View dy = grad_view(n, *ps, op.out, d_out, d_ld);
@@ -489,18 +392,12 @@ struct BackwardRun {
     int rc = PCMI_OK;
     if (op.type == PCMI_OP_CONV) {
       const pcmi_kmap_t* map = ps->has_map[i] ? &ps->maps[i] : nullptr;
-      if (wst != st) {  // dy is complete at this point of `st` (all its consumers were differentiated before)
-        PCMI_HIP_CHECK(hipEventRecord(n.ev_main[sidx], st));
-        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sidx], 0));
-        side_pending = true;
-      }
-      static const bool skip_wgrad = [] {  // timing experiments only (gradients are WRONG): the chain without its shadow
-        const char* e = getenv("PCMI_DEBUG_SKIP_WGRAD");
-        return e && e[0] == '1';
-      }();
-      if (!skip_wgrad)
-        rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose,
-                                    gdst + op.w_off, op.has_bias ? gdst + op.b_off : nullptr, gacc, wws->p, wws->cap, wst);
+      // dy is complete at this point of `st` (all its consumers were differentiated before)
+      PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
+      PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[0], 0));
+      side_pending = true;
+      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose, grads + op.w_off,
+                                  op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
       if (rc) return rc;
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
@@ -512,39 +409,15 @@ struct BackwardRun {
       View dr = {nullptr, 0};
       if (op.in2 >= 0) dr = grad_view(n, *ps, op.in2, d_out, d_ld);
       const float* stats0 = (const float*)(ps->act.p + ps->stat_off[i]);
-      float* dgamma = scratch_g;
-      float* dbeta = scratch_g + op.cout;
-      float* acc_g = grads + op.w_off;
-      float* acc_b = grads + op.b_off;
       const int64_t sp = ps->split[n.tensors[op.in].level];
-      const int n_seg = sp < n_in ? 2 : 1;
-      if (deferred) {  // the sums ARE this pass's parameter gradients: stored straight into the peer buffer
-        PCMI_REQUIRE(n_seg == 1, PCMI_ERR_UNSUPPORTED, "net_backward_pair: two-segment passes run solo");
-        dgamma = gdst + op.w_off;
-        dbeta = gdst + op.b_off;
-        acc_g = acc_b = nullptr;
-      }
-      static const bool seg_fused = [] {
-        const char* e = getenv("PCMI_BN_SEG_FUSED");
-        return !(e && e[0] == '0');
-      }();
-      if (n_seg == 2 && !seg_fused) {
-        for (int seg = 0; seg < 2 && !rc; ++seg) {
-          const int64_t r0 = seg ? sp : 0, cnt = seg ? n_in - sp : sp;
-          const float* stats = stats0 + seg * 3 * op.cout;
-          rc = bn_backward(dy.p + r0 * dy.ld, dy.ld, x.p + r0 * x.ld, x.ld, op.relu ? y.p + r0 * y.ld : nullptr, y.ld, cnt,
-                           op.cout, params + op.w_off, stats, stats + op.cout, dx.p + r0 * dx.ld, dx.ld,
-                           dr.p ? dr.p + r0 * dr.ld : nullptr, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps->ws.p,
-                           ps->ws.cap, st);
-        }
-      } else if (n_seg == 2)  // a segment = one forward call of the reference: own statistics, own sums; one launch pair
+      if (sp < n_in)  // a segment = one forward call of the reference: own statistics, own sums; one launch pair
         rc = bn_backward2(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, sp, op.cout, params + op.w_off, stats0,
-                          stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, acc_g, acc_b,
-                          ps->ws.p, ps->ws.cap, st);
+                          stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, grads + op.w_off,
+                          grads + op.b_off, ps->ws.p, ps->ws.cap, st);
       else
         rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats0,
-                         stats0 + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, dgamma, dbeta, acc_g, acc_b, ps->ws.p,
-                         ps->ws.cap, st);
+                         stats0 + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, scratch_g + op.cout,
+                         grads + op.w_off, grads + op.b_off, ps->ws.p, ps->ws.cap, st);
     } else {
       const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
       rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps->act.p + ps->stat_off[i]), n_in, op.cout, dx.p, dx.ld,
@@ -553,35 +426,17 @@ struct BackwardRun {
     if (rc) return rc;
     for (int b = 0; b < n_buckets; ++b)
       if (bucket_last[b] == i) {
-        if (deferred) {  // everything this pass contributes to bucket b is in the peer buffer behind this event
-          rc = join_side();
-          if (rc) return rc;
-          PCMI_HIP_CHECK(hipEventRecord(ps->bucket_ev[b], st));
-        } else {
-          rc = primary ? absorb_peer(b, bucket_lo_host[b], bucket_hi(b)) : join_side();
-          if (rc) return rc;
-          if (ready) ready(ready_ctx, b);
-        }
+        rc = join_side();
+        if (rc) return rc;
+        if (ready) ready(ready_ctx, b);
       }
     return PCMI_OK;
   }
 
   int end() {
-    int rc = join_side();
+    const int rc = join_side();
     if (rc) return rc;
-    if (shared) {
-      rc = move_to(own);  // the boundary events below belong to the pass's own stream
-      if (rc) return rc;
-    }
-    if (deferred) {
-      PCMI_HIP_CHECK(hipEventRecord(ps->bucket_ev[n_buckets], st));
-    } else if (primary) {
-      // no buckets: the whole peer buffer at once; with buckets: only ordering (the peer is done with its arenas)
-      rc = n_buckets == 0 ? absorb_peer(0, 0, n.param_extent) : absorb_peer(n_buckets, 0, 0);
-      if (rc) return rc;
-      peer->valid = false;
-    }
-    if (!deferred) ps->valid = false;
+    ps->valid = false;
     return PCMI_OK;
   }
 };
@@ -681,7 +536,7 @@ int pcmi_net_destroy(pcmi_net_t* net) {
 
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
-  size_t b = net->ws_side[0].cap + net->ws_side[1].cap + net->grads_peer.cap;
+  size_t b = net->ws_side[0].cap + net->ws_side[1].cap;
   for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap;
   *bytes = b;
   return PCMI_OK;
@@ -837,22 +692,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       if (train) {
         const int64_t sp = ps.split[n.tensors[op.in].level];
         float* stats1 = stats0 + 3 * op.cout;
-        static const bool seg_fused = [] {  // PCMI_BN_SEG_FUSED=0: one BatchNorm call per segment (A/B, debugging)
-          const char* e = getenv("PCMI_BN_SEG_FUSED");
-          return !(e && e[0] == '0');
-        }();
-        if (sp < n_in && !seg_fused) {
-          for (int seg = 0; seg < 2 && !rc; ++seg) {
-            const int64_t r0 = seg ? sp : 0, cnt = seg ? n_in - sp : sp;
-            float* stats = stats0 + seg * 3 * op.cout;
-            rc = bn_forward_train(x.p + r0 * x.ld, x.ld, cnt, op.cout, params + op.w_off, params + op.b_off, nullptr, nullptr,
-                                  op.momentum, op.eps, r.p ? r.p + r0 * r.ld : nullptr, r.ld, op.relu, y.p + r0 * y.ld, y.ld,
-                                  stats, stats + op.cout, stats + 2 * op.cout, ps.ws.p, ps.ws.cap, st);
-          }
-          if (op.running_mean)
-            ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
-                                       stats1, stats1 + 2 * op.cout};
-        } else if (sp < n_in) {  // both segments in one statistics launch + one apply launch; running estimates via the table
+        if (sp < n_in) {  // both segments in one statistics launch + one apply launch; running estimates via the table
           rc = bn_forward_train2(x.p, x.ld, n_in, sp, op.cout, params + op.w_off, params + op.b_off, op.eps, r.p, r.ld, op.relu,
                                  y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, 3 * op.cout, ps.ws.p, ps.ws.cap, st);
           if (op.running_mean)
@@ -913,67 +753,7 @@ int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_l
   job.d_out = d_out;
   job.d_ld = d_ld;
   job.st = as_stream(stream);
-  job.role = BackwardJob::SOLO;
   return run_backward(*net, job, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
-}
-
-int pcmi_net_backward_pair(pcmi_net_t* net, const float* d_out0, int64_t d_ld0, const float* d_out1, int64_t d_ld1,
-                           const float* params, float* grads, const int64_t* bucket_lo_host, int n_buckets,
-                           pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream) {
-  PCMI_REQUIRE(net && d_out0 && d_out1 && params && grads, PCMI_ERR_INVALID, "net_backward_pair: null argument");
-  PCMI_REQUIRE(net->passes.size() >= 2 && net->passes[0].valid && net->passes[1].valid, PCMI_ERR_INVALID,
-               "net_backward_pair: passes 0 and 1 need a training-mode forward each");
-  pcmi_net& n = *net;
-  hipStream_t st = as_stream(stream);
-  const X3TableScope x3_scope(n, params);
-  int rc = ensure_streams(n);
-  if (rc) return rc;
-  if (!n.chain1) PCMI_HIP_CHECK(hipStreamCreateWithFlags(&n.chain1, hipStreamNonBlocking));  // only if ever used
-  if ((size_t)n.param_extent * sizeof(float) > n.grads_peer.cap) {
-    rc = n.grads_peer.reserve((size_t)n.param_extent * sizeof(float), st);
-    if (rc) return rc;
-    // once: the gaps between parameters stay zero ever after (ops only store into parameter ranges)
-    PCMI_HIP_CHECK(hipMemsetAsync(n.grads_peer.p, 0, n.grads_peer.cap, st));
-  }
-  // pass 1 on the executor's second chain stream, after whatever `st` holds now (d_out1, the zero-filled grads)
-  PCMI_HIP_CHECK(hipEventRecord(n.ev_fork, st));
-  PCMI_HIP_CHECK(hipStreamWaitEvent(n.chain1, n.ev_fork, 0));
-  BackwardJob j1;
-  j1.pass = 1;
-  j1.d_out = d_out1;
-  j1.d_ld = d_ld1;
-  j1.st = n.chain1;
-  j1.role = BackwardJob::DEFERRED;
-  BackwardJob j0;
-  j0.pass = 0;
-  j0.d_out = d_out0;
-  j0.d_ld = d_ld0;
-  j0.st = st;
-  j0.role = BackwardJob::PRIMARY;
-  BackwardRun r1(n, j1, params, grads, bucket_lo_host, n_buckets, nullptr, nullptr);
-  BackwardRun r0(n, j0, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
-  rc = r1.begin();
-  if (rc) return rc;
-  rc = r0.begin();
-  if (rc) return rc;
-  static const int own_from = [] {  // PCMI_PAIR_OWN_FROM: first level whose ops pass 1 runs on its own stream (0 = all)
-    const char* e = getenv("PCMI_PAIR_OWN_FROM");
-    return e ? atoi(e) : 1;
-  }();
-  if (own_from > 0) {
-    r1.shared = st;
-    r1.own = n.chain1;
-    r1.own_from = own_from;
-  }
-  // op by op, pass 1 first: its bucket events are recorded before pass 0 waits for them
-  for (int i = (int)n.ops.size() - 1; i >= 0; --i) {
-    rc = r1.step(i);
-    if (rc) return rc;
-    rc = r0.step(i);
-    if (rc) return rc;
-  }
-  rc = r1.end();
-  return rc ? rc : r0.end();
 }
 
 }  // extern "C"

@@ -624,8 +624,7 @@ namespace pcmi {
 // workgroups per row tile: enough to put ~2 workgroups on every CU, at most one split per other-operand tile
 static int nce_splits(int64_t n) {
   const int64_t nb = ceil_div(n, kTile);
-  const char* e = getenv("PCMI_NCE_SPLITS");
-  const int64_t want = e ? atoll(e) : ceil_div(2 * (int64_t)num_cu(), nb);
+  const int64_t want = ceil_div(2 * (int64_t)num_cu(), nb);
   return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, nb), 32));
 }
 static int64_t nce_span(int64_t n, int splits) { return ceil_div(ceil_div(n, kTile), splits) * kTile; }

@@ -511,13 +511,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a
   *reinterpret_cast<float4*>(out + r * out_ld + sub * 4) = o;
 }
 
-static bool fuse_final_enabled() {  // PCMI_BN_FUSE_FINAL=0: always the separate final kernels (A/B, debugging)
-  static const bool on = [] {
-    const char* e = getenv("PCMI_BN_FUSE_FINAL");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+static bool fuse_final_enabled() { return true; }  // (the separate final kernels serve more than 256 row blocks only)
 
 static int check_rows(const char* who, const void* p, int64_t ld, int c) {
   PCMI_REQUIRE(p && c > 0 && c % 4 == 0 && c <= 1024 && ld % 4 == 0 && ld >= c && (uintptr_t)p % 16 == 0, PCMI_ERR_INVALID,

@@ -81,19 +81,12 @@ __device__ __forceinline__ void store_b_regs(const v4f (&breg)[NT * KC / 32], fl
   }
 }
 
-// SK ("stream-K" over the offsets): a tile's cost is proportional to the number of offsets that occur in it (9..27
-// after the mask sort), and 683 tiles on 768 resident workgroup slots is ONE round whose length the unluckiest CU
-// sets -- the waves were alive for 68 % of the kernel.  In SK mode the launch is a fixed set of resident workgroups;
-// the (tile, occupied offset) units of the whole level are numbered tile-major (map.tile_pref) and workgroup g
-// takes units [g*per, (g+1)*per): whole tiles are written as usual, the at most two tiles a workgroup shares
-// with its neighbours go to partial slots [g][0 = its first piece | 1 = its last piece] and
-// sk_fixup_kernel adds the pieces of a split tile in workgroup order (deterministic).
 // KC: contraction channels per staged chunk (= per barrier).  32 everywhere except the narrow-slice launches of the
 // small levels (NT = 1 with KC = 128, NT = 2 with KC = 64): there a 32-channel step is 16 MFMAs per wave -- 0.4 us,
 // shorter than the L2 latency of the next step's gathers and weights, so the kernel ran at one memory latency per
 // step (27 steps x ~0.9 us for a 256-channel conv over 1.3k rows); a deeper chunk gives every barrier 4x the matrix
 // work and 4x the loads in flight.  Those variants trade the third wave per SIMD for the larger operand rings.
-template <int NT, int RW, bool WT, bool PAIR, bool SK = false, int KC = kKC>
+template <int NT, int RW, bool WT, bool PAIR, int KC = kKC>
 // min 3 waves/SIMD: with this bound hipcc keeps the accumulators in plain VGPRs (<= 158 in total, no scratch);
 // without it it split them into AGPRs at 170-220 registers total and 2 waves/SIMD
 __global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvArgs a) {
@@ -111,40 +104,11 @@ __global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvA
   __shared__ int32_t s_idx[KSLOTS][TM];
   __shared__ int32_t s_orow[TM];
   __shared__ int32_t s_klist[KSLOTS];
-  __shared__ int32_t s_kabs[KSLOTS];  // offset index of a slot (weight slice = wsel[s_kabs])
   __shared__ int32_t s_nk;
   __shared__ int64_t s_tile[2];
 
   const int n0 = blockIdx.y * NS;
-
-  // ---- unit range of this workgroup (SK) ------------------------------------------------------
-  int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
-  bool sk_first = true;
-  if constexpr (SK) {
-    const int G = (int)gridDim.x;  // multiple of 8: workgroup b (on XCD b % 8) -> logical g in that XCD's range
-    sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
-    const int U = a.sk_pref[a.sk_tiles];
-    const int per = (U + G - 1) / G;
-    sk_u = sk_g * per;
-    sk_u1 = min(U, sk_u + per);
-    if (sk_u >= sk_u1) return;
-    if (threadIdx.x == 0) {  // last tile whose first unit is <= sk_u
-      int lo = 0, hi = a.sk_tiles - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (a.sk_pref[mid] <= sk_u) lo = mid; else hi = mid - 1;
-      }
-      s_tile[0] = lo;
-    }
-    __syncthreads();
-    sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);  // wave-uniform: keep the piece bookkeeping in SGPRs
-  }
-  for (;;) {  // one pass per tile piece (exactly one when !SK)
-  bool sk_whole = true;
-  int sk_next_u = 0;
-  int t = threadIdx.x;
-  // SK: opaque per pass, otherwise hipcc hoists every lane-dependent address out of the piece loop (+35 VGPRs)
-  if constexpr (SK) asm volatile("" : "+v"(t));
+  const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int rg = wave % RW, kg = wave / RW;
@@ -178,35 +142,6 @@ __global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvA
     if (t == 0) {
       s_klist[0] = 0;  // slot of s_idx; the weight slice comes from k_single
       s_nk = 1;
-    }
-  } else if constexpr (SK) {
-    // piece = offsets [jb, je) of the occupied-offset list of tile sk_tile
-    const int64_t row0 = (int64_t)sk_tile * TM;
-    const uint32_t tmask = a.sk_mask[sk_tile];
-    const int pref = a.sk_pref[sk_tile], nk_t = __popc(tmask);
-    const int jb = sk_u - pref, je = min(sk_u1 - pref, nk_t);
-    sk_whole = (jb == 0 && je == nk_t);
-    sk_next_u = pref + je;
-    if (t == 0) {
-      int j = 0, c = 0;
-      for (int k = 0; k < a.K; ++k)
-        if ((tmask >> k) & 1u) {
-          if (j >= jb && j < je) {
-            s_kabs[c] = k;
-            s_klist[c] = c;
-            ++c;
-          }
-          ++j;
-        }
-      s_nk = c;
-    }
-    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
-    __syncthreads();
-    const int cnt = je - jb;
-    for (int p = t; p < cnt * TM; p += 256) {
-      const int kk = p / TM, rr = p - kk * TM;
-      const int64_t row = row0 + rr;
-      s_idx[kk][rr] = row < a.n_rows ? a.nbr[(int64_t)s_kabs[kk] * a.n_rows + row] : -1;
     }
   } else {
     // Workgroup b is observed to run on XCD b % 8 (never relied upon for correctness): give every XCD a
@@ -261,7 +196,7 @@ __global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvA
   auto load_b = [&](int step) {
     const int kslot = s_klist[step / nch];
     const int c0 = (step % nch) * KC;
-    const int wk = PAIR ? a.wsel[k_single] : (SK ? a.wsel[s_kabs[kslot]] : a.wsel[kbeg_blk + kslot]);
+    const int wk = PAIR ? a.wsel[k_single] : a.wsel[kbeg_blk + kslot];
     load_b_regs<NT, WT, KC>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
   };
   auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB, KC>(breg, s_f + buf * (KC * LDB), t); };
@@ -364,18 +299,7 @@ __global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvA
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
-  if (SK && !sk_whole) {
-    // a piece of a tile shared with the neighbouring workgroups: dense [128][N] slot, summed by sk_fixup_kernel
-    if (kg == 0) {
-      float* pp = a.sk_part + ((int64_t)(2 * sk_g + (sk_first ? 0 : 1)) * TM + rg * 32) * a.N + n0 + r;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int i = (j & 3) + 8 * (j >> 2) + 4 * h;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) pp[(int64_t)i * a.N + nt * 32] = acc[nt][j];
-      }
-    }
-  } else if (kg == 0) {
+  if (kg == 0) {
     float* outp = a.out + (PAIR ? 0 : (int64_t)blockIdx.z * a.split_stride);
     float bv[NT];
 #pragma unroll
@@ -396,20 +320,17 @@ __global__ __launch_bounds__(256, KC > 32 ? 2 : 3) void spconv_mfma_kernel(ConvA
       }
     }
   }
-  if constexpr (!SK) {
-    break;
-  } else {
-    sk_u = sk_next_u;
-    ++sk_tile;
-    sk_first = false;
-    if (sk_u >= sk_u1) break;
-    __syncthreads();  // s_idx / s_orow / the staging area are rewritten by the next piece
-  }
-  }  // for (;;)
 }
 
 // ---- 16-row variant for the 128-row tiles ------------------------------------------------------------------------
-// Same formulation, operands and LDS staging as spconv_mfma_kernel<NT, 4, WT, false, SK>, but on
+// SK ("stream-K" over the offsets): a tile's cost is proportional to the number of offsets that occur in it (9..27
+// after the mask sort), and 683 tiles on 768 resident workgroup slots is ONE round whose length the unluckiest CU
+// sets -- the waves were alive for 68 % of the kernel.  In SK mode (these kernels and spconv16x_kernel) the launch is a fixed set of resident workgroups;
+// the (tile, occupied offset) units of the whole level are numbered tile-major (map.tile_pref) and workgroup g
+// takes units [g*per, (g+1)*per): whole tiles are written as usual, the at most two tiles a workgroup shares
+// with its neighbours go to partial slots [g][0 = its first piece | 1 = its last piece] and
+// sk_fixup_kernel adds the pieces of a split tile in workgroup order (deterministic).
+// Same formulation, operands and LDS staging as spconv_mfma_kernel<NT, 4, WT, false>, but on
 // v_mfma_f32_16x16x4_f32 (same peak): lane l = (i = l & 15, kk = l >> 4) supplies A[i][kk] and B[kk][j = i].  A wave
 // still owns 32 rows, now as TWO independent 16-row groups, and skips an offset per GROUP: with 32-row groups the
 // matrix pipe issued 1.18x the algorithmic FLOPs on the mask-sorted level-1 maps (PMC), the zero rows of waves whose
@@ -424,314 +345,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PCMI_CONV16_W4
 #define PCMI_CONV16_W4 1
 #endif
-// timing ablations of spconv16_kernel (results are WRONG for != 0; scripts/ablate_conv16.sh builds them into separate
-// libraries): 1 no group skipping, 2 contiguous rows instead of the gather, 3 no B store + barrier per step,
-// 4 no MFMA, 5 no A loads, 9 per-wave cycle accounting, 10 (pipelined form) no progress-based issue priority
-#ifndef PCMI_ABLATE
-#define PCMI_ABLATE 0
-#endif
-#if PCMI_ABLATE == 9  // per-wave cycle accounting of spconv16_kernel (s_memtime), read back by pcmi_debug_conv_prof
-__device__ unsigned long long g_conv16_prof[4096 * 12];
-#define PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
-#define PROF_ADD(slot, d) prof[slot] += (d)
-#else
-#define PROF_T(v)
-#define PROF_ADD(slot, d)
-#endif
 __host__ __device__ constexpr int kConv16Waves(int nt) { return (PCMI_CONV16_W4 && nt <= 3) ? 4 : 3; }
 
-template <int NT, bool WT, bool SK>
-__global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArgs a) {
-  constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
-  constexpr int LDB = NS + 4;
-  constexpr int KSLOTS = PCMI_MAX_KERNEL_VOLUME;
-  __shared__ __attribute__((aligned(16))) float s_f[2 * kKC * LDB];
-  __shared__ int32_t s_idx[KSLOTS][TM];
-  __shared__ int32_t s_orow[TM];
-  __shared__ int32_t s_klist[KSLOTS];
-  __shared__ int32_t s_kabs[KSLOTS];
-  __shared__ int32_t s_nk;
-  __shared__ int64_t s_tile[2];
-
-  const int n0 = blockIdx.y * NS;
-  int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
-  bool sk_first = true;
-#if PCMI_ABLATE == 9
-  unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  prof[8] = __builtin_readcyclecounter();
-  prof[9] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
-  prof[10] = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
-#endif
-  if constexpr (SK) {
-    const int G = (int)gridDim.x;
-    sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
-    const int U = a.sk_pref[a.sk_tiles];
-    const int per = (U + G - 1) / G;
-    sk_u = sk_g * per;
-    sk_u1 = min(U, sk_u + per);
-    if (sk_u >= sk_u1) return;
-    if (threadIdx.x == 0) {
-      int lo = 0, hi = a.sk_tiles - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (a.sk_pref[mid] <= sk_u) lo = mid; else hi = mid - 1;
-      }
-      s_tile[0] = lo;
-    }
-    __syncthreads();
-    sk_tile = __builtin_amdgcn_readfirstlane((int)s_tile[0]);
-  }
-  for (;;) {  // one pass per tile piece (exactly one when !SK)
-  PROF_T(pt_piece);
-  bool sk_whole = true;
-  int sk_next_u = 0;
-  int t = threadIdx.x;
-  if constexpr (SK) asm volatile("" : "+v"(t));  // see spconv_mfma_kernel
-  const int lane = t & 63, wave = t >> 6;
-  const int i = lane & 15, kk = lane >> 4;
-  int kbeg = 0;
-  if constexpr (SK) {
-    const int64_t row0 = (int64_t)sk_tile * TM;
-    const uint32_t tmask = a.sk_mask[sk_tile];
-    const int pref = a.sk_pref[sk_tile], nk_t = __popc(tmask);
-    const int jb = sk_u - pref, je = min(sk_u1 - pref, nk_t);
-    sk_whole = (jb == 0 && je == nk_t);
-    sk_next_u = pref + je;
-    if (t == 0) {
-      int j = 0, c = 0;
-      for (int k = 0; k < a.K; ++k)
-        if ((tmask >> k) & 1u) {
-          if (j >= jb && j < je) {
-            s_kabs[c] = k;
-            s_klist[c] = c;
-            ++c;
-          }
-          ++j;
-        }
-      s_nk = c;
-    }
-    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
-    __syncthreads();
-    const int cnt = je - jb;
-    for (int p = t; p < cnt * TM; p += 256) {
-      const int q = p / TM, rr = p - q * TM;
-      const int64_t row = row0 + rr;
-      s_idx[q][rr] = row < a.n_rows ? a.nbr[(int64_t)s_kabs[q] * a.n_rows + row] : -1;
-    }
-  } else {
-    int64_t tile = blockIdx.x;
-    if (a.xcd_tiles > 0) {
-      tile = (int64_t)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
-      if (tile * TM >= a.n_rows) return;
-    }
-    const int64_t row0 = tile * TM;
-    kbeg = (int)((int64_t)a.K * blockIdx.z / a.ksplit);
-    const int kend = (int)((int64_t)a.K * (blockIdx.z + 1) / a.ksplit);
-    if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
-    for (int p = t; p < (kend - kbeg) * TM; p += 256) {
-      const int q = p / TM, rr = p - q * TM;
-      const int64_t row = row0 + rr;
-      int32_t v = -1;
-      if (row < a.n_rows) v = a.nbr ? a.nbr[(int64_t)(kbeg + q) * a.n_rows + row] : (int32_t)row;
-      s_idx[q][rr] = v;
-    }
-    __syncthreads();
-    if (t < 64) {  // offsets with at least one neighbour in this tile
-      int nk = 0;
-      for (int q = 0; q < kend - kbeg; ++q) {
-        bool any = false;
-        for (int rr = t; rr < TM; rr += 64) any |= (s_idx[q][rr] >= 0);
-        if (__any(any)) {
-          if (t == 0) s_klist[nk] = q;
-          ++nk;
-        }
-      }
-      if (t == 0) s_nk = nk;
-    }
-  }
-  __syncthreads();
-  const int nk = s_nk;
-  const int nch = a.C / kKC;
-  const int nsteps = nk * nch;
-
-  f32x4 acc[2][CTN];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int ct = 0; ct < CTN; ++ct) acc[g][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  v4f breg[NT];
-  auto load_b = [&](int step) {
-    const int kslot = s_klist[step / nch];
-    const int c0 = (step % nch) * kKC;
-    const int wk = SK ? a.wsel[s_kabs[kslot]] : a.wsel[kbeg + kslot];
-    load_b_regs<NT, WT>(breg, a.w + (int64_t)wk * a.w_kstride, a.w_sc, a.w_sn, c0, n0, t);
-  };
-  auto store_b = [&](int buf) { store_b_regs<NT, WT, LDB>(breg, s_f + buf * (kKC * LDB), t); };
-  // A: [group][16-channel block] float4 of this lane's row, one 32-channel step ahead; va: which groups have a row
-  float4 a0[2][2], a1[2][2];
-  int va0 = 0, va1 = 0;
-  auto load_a = [&](int step, float4 (&dst)[2][2]) -> int {
-    const int kslot = s_klist[step / nch];
-    const int c0 = (step % nch) * kKC;
-    int valid = 0;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      int32_t idx = s_idx[kslot][wave * 32 + g * 16 + i];
-      if constexpr (PCMI_ABLATE == 2) {
-        if (idx >= 0) idx = (int32_t)(((SK ? (int64_t)sk_tile : (int64_t)blockIdx.x) * TM + wave * 32 + g * 16 + i) % a.n_rows);
-      }
-      if (PCMI_ABLATE == 5) {
-        dst[g][0] = dst[g][1] = make_float4(1.f, 0.f, 0.f, 0.f);
-      } else if (idx >= 0) {
-        const float* xp = a.x + (int64_t)idx * a.x_ld + c0 + 4 * kk;
-        dst[g][0] = *reinterpret_cast<const float4*>(xp);
-        dst[g][1] = *reinterpret_cast<const float4*>(xp + 16);
-      } else {
-        dst[g][0] = dst[g][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      valid |= __any(idx >= 0) ? (1 << g) : 0;
-    }
-    return PCMI_ABLATE == 1 ? 3 : valid;
-  };
-
-  PROF_T(pt_pro);
-  PROF_ADD(0, pt_pro - pt_piece);
-  if (nsteps > 0) {
-    load_b(0);
-    va0 = load_a(0, a0);
-    store_b(0);
-    __syncthreads();
-    PROF_T(pt_fill);
-    PROF_ADD(1, pt_fill - pt_pro);
-    for (int step = 0; step < nsteps; ++step) {
-      const bool more = step + 1 < nsteps;
-      PROF_T(pt0);
-      if (more) load_b(step + 1);
-      if (more) va1 = load_a(step + 1, a1);
-      PROF_T(pt1);
-      PROF_ADD(2, pt1 - pt0);
-      PROF_ADD(7, (unsigned long long)(((va0 & 1) + ((va0 >> 1) & 1)) * 8 * CTN));
-      if constexpr (PCMI_ABLATE == 4) {
-        acc[0][0][0] += a0[0][0].x + a0[0][1].y + a0[1][0].z + a0[1][1].w;
-      } else if (va0) {
-        // B fragments PF contraction steps ahead of their MFMAs (register ring, order pinned by sched_barrier)
-        const float* sb = s_f + (step & 1) * (kKC * LDB) + i + (4 * kk) * LDB;
-        constexpr int QN = 8, PF = 2;  // 8 contraction steps of 4 channels per lane-quad; >= 256 NT cycles ahead
-        float bf[PF][CTN];
-#pragma unroll
-        for (int q = 0; q < PF; ++q)
-#pragma unroll
-          for (int ct = 0; ct < CTN; ++ct) bf[q][ct] = sb[(16 * (q >> 2) + (q & 3)) * LDB + ct * 16];
-        __builtin_amdgcn_sched_barrier(0);
-        const bool g0 = (va0 & 1) != 0, g1 = (va0 & 2) != 0;
-#pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          const float4 x0 = a0[0][q >> 2], x1 = a0[1][q >> 2];
-          const float av0 = (q & 3) == 0 ? x0.x : (q & 3) == 1 ? x0.y : (q & 3) == 2 ? x0.z : x0.w;
-          const float av1 = (q & 3) == 0 ? x1.x : (q & 3) == 1 ? x1.y : (q & 3) == 2 ? x1.z : x1.w;
-          if (g0) {
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct)
-              acc[0][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bf[q % PF][ct], acc[0][ct], 0, 0, 0);
-          }
-          if (g1) {
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct)
-              acc[1][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bf[q % PF][ct], acc[1][ct], 0, 0, 0);
-          }
-          if (q + PF < QN) {
-            const int qq = q + PF;
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct) bf[q % PF][ct] = sb[(16 * (qq >> 2) + (qq & 3)) * LDB + ct * 16];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      PROF_T(pt2);
-      PROF_ADD(3, pt2 - pt1);
-      if constexpr (PCMI_ABLATE == 9) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PROF_T(pt2b);
-        PROF_ADD(4, 1);  // steps (the vmcnt(0) wait measured 0.3 % of the wave time)
-        if (more) store_b((step + 1) & 1);
-        __syncthreads();
-        PROF_T(pt3);
-        PROF_ADD(5, pt3 - pt2b);
-      } else if constexpr (PCMI_ABLATE == 3) {
-        if (more && step < 1) store_b((step + 1) & 1);  // keeps the loaded registers live
-        else if (more) asm volatile("" :: "v"(breg[0].x), "v"(breg[NT - 1].w));
-      } else {
-        if (more) store_b((step + 1) & 1);
-        __syncthreads();
-      }
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        a0[g][0] = a1[g][0];
-        a0[g][1] = a1[g][1];
-      }
-      va0 = va1;
-    }
-  }
-
-  // ---- epilogue: D[row = 4 kk + r][col = i] of every 16x16 tile --------------------------------------------------
-  if (SK && !sk_whole) {
-    float* pp = a.sk_part + ((int64_t)(2 * sk_g + (sk_first ? 0 : 1)) * TM + wave * 32) * a.N + n0 + i;
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rl = g * 16 + 4 * kk + r;
-#pragma unroll
-        for (int ct = 0; ct < CTN; ++ct) pp[(int64_t)rl * a.N + ct * 16] = acc[g][ct][r];
-      }
-  } else {
-    float* outp = a.out + (int64_t)blockIdx.z * a.split_stride;
-    float bv[CTN];
-#pragma unroll
-    for (int ct = 0; ct < CTN; ++ct) bv[ct] = a.bias ? a.bias[n0 + ct * 16 + i] : 0.f;
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int32_t orow = s_orow[wave * 32 + g * 16 + 4 * kk + r];
-        if (orow >= 0) {
-          float* op = outp + (int64_t)orow * a.out_ld + n0 + i;
-          if (a.accumulate) {
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] += acc[g][ct][r] + bv[ct];
-          } else {
-#pragma unroll
-            for (int ct = 0; ct < CTN; ++ct) op[ct * 16] = acc[g][ct][r] + bv[ct];
-          }
-        }
-      }
-  }
-  PROF_T(pt_end);
-  PROF_ADD(6, pt_end - pt_piece);
-#if PCMI_ABLATE == 9
-  if (!SK || sk_next_u >= sk_u1) {
-    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
-      unsigned long long* o = g_conv16_prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12;
-      prof[11] = __builtin_readcyclecounter();
-      for (int q = 0; q < 12; ++q) o[q] = prof[q];
-    }
-  }
-#endif
-  if constexpr (!SK) {
-    break;
-  } else {
-    sk_u = sk_next_u;
-    ++sk_tile;
-    sk_first = false;
-    if (sk_u >= sk_u1) break;
-    __syncthreads();
-  }
-  }  // for (;;)
-}
-
-// ---- software-pipelined form of spconv16_kernel ---------------------------------------------------------------------
-// Per-wave cycle accounting of spconv16_kernel (scripts/conv16_prof.py, profiles/r02_conv16_cycles.txt): a wave spent
+// ---- the kernel (software-pipelined; round 2's unpipelined form -- same operands, bit-identical results -- is gone) ----
+// Per-wave cycle accounting of the unpipelined form (profiles/r02_stall_attribution.txt): a wave spent
 // 31 % of its life ISSUING the next step's loads (two dependent LDS look-ups, a kernarg look-up, 64-bit address
 // arithmetic, exec-masked gathers), 33 % in its MFMA phase and 23 % at the per-step barrier; no phase of a wave
 // overlapped another phase of the same wave, so the matrix pipe depended on the other three waves of the SIMD being
@@ -743,8 +360,7 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16_kernel(ConvArg
 //   * one LDS look-up per offset ({table row, weight slice byte offset}), reused by the C / 32 chunk steps of the offset;
 //   * the look-up, the weight loads and the gathers sit after the MFMAs of contraction steps 0, 1 and 2 of the running
 //     chunk, each consuming what the previous stage requested, so none of them waits.
-// Operands, accumulation order and results are those of spconv16_kernel (bit-identical).  Needs the gathered operand
-// to be < 2 GiB (the launcher falls back otherwise).
+// Needs the gathered operand to be < 2 GiB (the launcher falls back to spconv_mfma_kernel otherwise).
 template <int NT, bool WT, bool SK>
 __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvArgs a) {
   constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;
@@ -763,12 +379,6 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvAr
   const int n0 = blockIdx.y * NS;
   int sk_g = 0, sk_tile = 0, sk_u = 0, sk_u1 = 0;
   bool sk_first = true;
-#if PCMI_ABLATE == 9
-  unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  prof[8] = __builtin_readcyclecounter();
-  prof[9] = __builtin_amdgcn_s_getreg(63492);
-  prof[10] = __builtin_amdgcn_s_getreg(63508);
-#endif
   if constexpr (SK) {
     const int G = (int)gridDim.x;
     sk_g = (int)(blockIdx.x & 7) * (G / 8) + (int)(blockIdx.x >> 3);
@@ -802,7 +412,6 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvAr
   const int sk_total = SK ? sk_u1 - sk_u : 0;  // chunk steps of this workgroup
   int sk_done = 0, prio_qtr = -1;
   for (;;) {  // one pass per tile piece (exactly one when !SK)
-  PROF_T(pt_piece);
   bool sk_whole = true;
   int sk_next_u = 0, sk_c0 = 0, sk_steps = 0;  // SK: first chunk of the piece's first offset; steps of the piece
   int t = threadIdx.x;
@@ -935,26 +544,20 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvAr
     dst[1][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1, soff, 0));
     dst[0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0 + 64, soff, 0));
     dst[1][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1 + 64, soff, 0));
-    return PCMI_ABLATE == 1 ? 3 : va;
+    return va;
   };
 
-  PROF_T(pt_pro);
-  PROF_ADD(0, pt_pro - pt_piece);
   if (nsteps > 0) {
     stage_meta();
     stage_b(true);
     va0 = stage_a(a0, true);
     store_b(0);
     __syncthreads();
-    PROF_T(pt_fill);
-    PROF_ADD(1, pt_fill - pt_pro);
     // one chunk step on operand set `cur`, requesting the next one into `nxt` (two sets, swapped every step: no copies,
     // and the wait for a gather sits at its first use)
     auto do_step = [&](int step, v4f (&cur)[2][2], int va_cur, v4f (&nxt)[2][2], int& va_nxt) {
       const bool more = step + 1 < nsteps;
-      PROF_T(pt1);
-      PROF_ADD(7, (unsigned long long)(((va_cur & 1) + ((va_cur >> 1) & 1)) * 8 * CTN));
-      if constexpr (SK && PCMI_ABLATE != 10) {
+      if constexpr (SK) {
         // issue priority falls with the workgroup's progress through its (equal) share of units: the four workgroups
         // of a CU otherwise finish staggered (oldest first), and the last ones run with a half-empty matrix pipe
         const int qtr = __builtin_amdgcn_readfirstlane(((sk_done + step) * 4) / max(sk_total, 1));
@@ -1001,13 +604,8 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvAr
         if (q == 2) va_nxt = stage_a(nxt, more);
         __builtin_amdgcn_sched_barrier(0);
       }
-      PROF_T(pt2);
-      PROF_ADD(3, pt2 - pt1);
-      PROF_ADD(4, 1);
       if (more) store_b((step + 1) & 1);
       __syncthreads();
-      PROF_T(pt3);
-      PROF_ADD(5, pt3 - pt2);
     };
     for (int step = 0; step < nsteps; step += 2) {
       do_step(step, a0, va0, a1, va1);
@@ -1048,17 +646,6 @@ __global__ __launch_bounds__(256, kConv16Waves(NT)) void spconv16p_kernel(ConvAr
         }
       }
   }
-  PROF_T(pt_end);
-  PROF_ADD(6, pt_end - pt_piece);
-#if PCMI_ABLATE == 9
-  if (!SK || sk_next_u >= sk_u1) {
-    if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && blockIdx.x < 1024) {
-      unsigned long long* o = g_conv16_prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 12;
-      prof[11] = __builtin_readcyclecounter();
-      for (int q = 0; q < 12; ++q) o[q] = prof[q];
-    }
-  }
-#endif
   if constexpr (!SK) {
     break;
   } else {
@@ -1241,20 +828,6 @@ static int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
 
 constexpr int kStreamKDefaultMinTiles = 256;  // unit-balanced launch from 256 tiles (32768 rows); PCMI_SPCONV_STREAMK=0 turns it off
 
-// unit-balanced launch (128-row tiles, no pair mode)
-template <bool WT>
-static int launch_sk(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
-  switch (NT) {
-    case 1: spconv_mfma_kernel<1, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
-    case 2: spconv_mfma_kernel<2, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
-    case 3: spconv_mfma_kernel<3, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
-    case 4: spconv_mfma_kernel<4, 4, WT, false, true><<<grid, 256, 0, st>>>(a); break;
-    default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
-  }
-  PCMI_LAUNCH_CHECK();
-  return PCMI_OK;
-}
-
 // PCMI_SPCONV_STREAMK: minimum number of 128-row tiles for the unit-balanced launch (0 = never).
 static int64_t sk_min_tiles() {  // read per call: the parity test compares both launches in one process
   const char* e = getenv("PCMI_SPCONV_STREAMK");
@@ -1281,12 +854,6 @@ static bool conv16_enabled(int64_t n_rows, int64_t x_bytes) {
   return min_rows > 0 && n_rows >= min_rows && x_bytes <= 0x7FFFFF00ll;
 }
 
-// PCMI_CONV16_PIPE=0: the unpipelined spconv16_kernel (A/B and the parity test of the two forms)
-static bool conv16_pipelined() {
-  const char* e = getenv("PCMI_CONV16_PIPE");
-  return !e || atoi(e) != 0;
-}
-
 // The split-precision form (spconv_x3.hip: fp32 operands as three bf16 terms on the bf16 matrix cores) takes the
 // matrix-bound launches of the 16-row kernel (>= 64 channels on both sides); PCMI_CONV16_X3=0: the fp32-MFMA kernel.
 static bool conv16_x3_on() {
@@ -1294,70 +861,41 @@ static bool conv16_x3_on() {
   return !e || atoi(e) != 0;
 }
 static bool conv16_x3(int NT, int C, int N) { return conv16_x3_on() && NT >= 2 && NT <= 4 && C >= 64 && N >= 64; }
-// PCMI_X3_MAXNT=2: 128-wide outputs as two 64-wide slices (NT = 4 holds two weight blocks of 24 KiB in LDS and 190+
-// registers: 2 waves per SIMD; two NT = 2 slices gather and split the rows twice but run 3 waves per SIMD)
-static int x3_max_nt() {
-  const char* e = getenv("PCMI_X3_MAXNT");
-  return e ? atoi(e) : 4;
-}
-// slice width of the 128-row launches of a level with >= 8192 rows (make_plan + the override above); the executor packs
-// the weights for exactly this width ahead of the launches
+// slice width of the 128-row launches of a level with >= 8192 rows (as make_plan); the executor packs the weights for
+// exactly this width ahead of the launches.  (128-wide outputs as two 64-wide slices -- 3 instead of 2 waves per SIMD --
+// lost stand-alone, 0.186 vs 0.170 ms, and tied in the step: profiles/r02cd_x3_step_ab.txt.)
 int x3_nt_for(int N) {
   if (N % 32 != 0 || !conv16_x3_on()) return 0;
   const int nt_all = N / 32;
-  int nt = nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
-  if (nt == 4 && x3_max_nt() < 4) nt = 2;
-  return nt;
+  return nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
 }
 // resident workgroups per CU of spconv16x_kernel (LDS: 2 weight blocks of 6 KiB x NT + the 13.5 KiB offset table)
 static int x3_workgroups(int NT) { return (NT <= 3 ? 3 : 2) * num_cu() / 8 * 8; }
 
 template <bool WT, bool SK>
 static int launch16(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
-  if (conv16_pipelined()) {
-    switch (NT) {
-      case 1: spconv16p_kernel<1, WT, SK><<<grid, 256, 0, st>>>(a); break;
-      case 2: spconv16p_kernel<2, WT, SK><<<grid, 256, 0, st>>>(a); break;
-      case 3: spconv16p_kernel<3, WT, SK><<<grid, 256, 0, st>>>(a); break;
-      case 4: spconv16p_kernel<4, WT, SK><<<grid, 256, 0, st>>>(a); break;
-      default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
-    }
-    PCMI_LAUNCH_CHECK();
-    return PCMI_OK;
-  }
   switch (NT) {
-    case 1: spconv16_kernel<1, WT, SK><<<grid, 256, 0, st>>>(a); break;
-    case 2: spconv16_kernel<2, WT, SK><<<grid, 256, 0, st>>>(a); break;
-    case 3: spconv16_kernel<3, WT, SK><<<grid, 256, 0, st>>>(a); break;
-    case 4: spconv16_kernel<4, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 1: spconv16p_kernel<1, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 2: spconv16p_kernel<2, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 3: spconv16p_kernel<3, WT, SK><<<grid, 256, 0, st>>>(a); break;
+    case 4: spconv16p_kernel<4, WT, SK><<<grid, 256, 0, st>>>(a); break;
     default: set_error("spconv: bad NT %d", NT); return PCMI_ERR_INVALID;
   }
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
 
-// PCMI_DEEP_CHUNK: deepest chunk of the narrow-slice launches: 64 (default; NT = 1 keeps 4 waves per SIMD, NT = 2 keeps
-// 3), 128 (NT = 1 only: 194 VGPRs, 2 waves per SIMD), 0 / 32 = 32-channel chunks everywhere (A/B)
-static int deep_chunk_max() {
-  const char* e = getenv("PCMI_DEEP_CHUNK");
-  return e ? atoi(e) : 64;
-}
-
-// 128-row tiles, narrow slices: KC = 128 / 64 (NT = 1), 64 (NT = 2) when the contraction size allows; false = not taken
+// 128-row tiles, narrow slices (NT <= 2, levels under 8192 rows): 64-channel chunks when the contraction size allows --
+// twice the matrix work and loads in flight per barrier (NT = 1 keeps 4 waves per SIMD, NT = 2 keeps 3; 128-channel
+// chunks cost a wave per SIMD and lost).  false = not taken.
 template <bool WT>
 static bool launch_deep(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
-  const int kc_max = deep_chunk_max();
-  if (kc_max < 64) return false;
-  if (NT == 1 && a.C % 128 == 0 && kc_max >= 128) {
-    spconv_mfma_kernel<1, 4, WT, false, false, 128><<<grid, 256, 0, st>>>(a);
-    return true;
-  }
   if (NT == 1 && a.C % 64 == 0) {
-    spconv_mfma_kernel<1, 4, WT, false, false, 64><<<grid, 256, 0, st>>>(a);
+    spconv_mfma_kernel<1, 4, WT, false, 64><<<grid, 256, 0, st>>>(a);
     return true;
   }
   if (NT == 2 && a.C % 64 == 0) {
-    spconv_mfma_kernel<2, 4, WT, false, false, 64><<<grid, 256, 0, st>>>(a);
+    spconv_mfma_kernel<2, 4, WT, false, 64><<<grid, 256, 0, st>>>(a);
     return true;
   }
   return false;
@@ -1411,12 +949,7 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair) {
     p.NT = (nt_all % 2 == 0) ? 2 : 1;
   if (!pair && K > 1) {
     const int64_t wgs = ceil_div(rows, 32 * p.RW) * (nt_all / p.NT);
-    static const int target_x10 = [] {  // workgroups aimed at, in tenths of a CU count (experiments: PCMI_KSPLIT_TARGET)
-      const char* e = getenv("PCMI_KSPLIT_TARGET");
-      const int v = e ? atoi(e) : 0;
-      return v > 0 ? v : 25;
-    }();
-    const int64_t target = (target_x10 * (int64_t)num_cu()) / 10;
+    const int64_t target = (25 * (int64_t)num_cu()) / 10;  // workgroups aimed at: 2.5 per CU
     if (wgs < target) p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
   }
   return p;
@@ -1496,13 +1029,13 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     a.perm = map->perm;
   }
   Plan p = make_plan(n_rows, N, a.K, false);
-  if (p.NT == 4 && p.RW == 4 && conv16_x3_on() && x3_max_nt() < 4 && C >= 64) p.NT = 2;
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
+  // (the unit-balanced launch exists for the 16-row kernels: an operand of >= 2 GiB, which they cannot address, takes the
+  //  whole-tile launch of spconv_mfma_kernel below)
   if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
-      map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64) {
-    const bool c16 = conv16_enabled(n_rows, x_rows * x_ld * 4);
-    const bool x3 = c16 && conv16_x3(p.NT, C, N);
-    const int G = x3 ? x3_workgroups(p.NT) : (c16 ? sk_workgroups(p.NT) : sk_workgroups(4));
+      map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64 && conv16_enabled(n_rows, x_rows * x_ld * 4)) {
+    const bool x3 = conv16_x3(p.NT, C, N);
+    const int G = x3 ? x3_workgroups(p.NT) : sk_workgroups(p.NT);
     const size_t part = sk_partial_bytes(n_rows, N, a.K);
     const size_t need = part + (x3 ? x3_pack_bytes(a.K, C, N) : 0);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1520,12 +1053,10 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
         rc = x3_pack_weights(a, p.NT, const_cast<void*>(a.wpack), st);
       }
       if (rc == PCMI_OK) rc = x3_launch(p.NT, true, a, grid, st);
-    } else if (c16)
+    } else
       rc = w_transposed ? launch16<true, true>(p.NT, a, grid, st) : launch16<false, true>(p.NT, a, grid, st);
-    else
-      rc = w_transposed ? launch_sk<true>(p.NT, a, grid, st) : launch_sk<false>(p.NT, a, grid, st);
     if (rc) return rc;
-    const int sub = (x3 || (c16 && conv16_pipelined())) ? C / kKC : 1;
+    const int sub = C / kKC;  // the shares of both kernels are counted in chunk steps
     sk_fixup_kernel<<<dim3((unsigned)a.sk_tiles), 256, 0, st>>>(a.sk_part, a.sk_pref, a.sk_tiles, G, a.perm, n_rows, N, bias,
                                                               out, out_ld, accumulate, sub);
     PCMI_LAUNCH_CHECK();
@@ -1676,18 +1207,5 @@ int pcmi_spconv_bwd_data(const float* gout, int64_t gout_ld, int64_t n_out, int 
 
 int pcmi_spconv_split_precision(void) { return conv16_x3_on() ? 1 : 0; }
 
-#if PCMI_ABLATE == 9
-int pcmi_debug_conv_prof(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv16_prof), sizeof(unsigned long long) * 4096 * 12) == hipSuccess ? PCMI_OK : PCMI_ERR_HIP;
-}
-#endif
-
-// diagnostic (scripts/): resident workgroups per CU of the level-1 kernels as the runtime computes them
-int pcmi_debug_conv_occupancy(int* conv16_nt3, int* conv16_nt4, int* mfma_nt3_sk) {
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(conv16_nt3, spconv16_kernel<3, false, true>, 256, 0);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(conv16_nt4, spconv16_kernel<4, false, true>, 256, 0);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(mfma_nt3_sk, spconv_mfma_kernel<3, 4, false, false, true>, 256, 0);
-  return e == hipSuccess ? PCMI_OK : PCMI_ERR_HIP;
-}
 
 }  // extern "C"

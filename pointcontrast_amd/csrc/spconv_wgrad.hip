@@ -142,15 +142,6 @@ __device__ inline void locate_chunk(const int64_t* offs, int mpk, int64_t M, int
   desc[4] = (e - b + chunk - 1) / chunk;
 }
 
-#ifndef PCMI_ABLATE
-#define PCMI_ABLATE 0
-#endif
-#if PCMI_ABLATE == 9  // per-wave cycle accounting (scripts/wgrad_prof.py)
-__device__ unsigned long long g_wgrad_prof[4096 * 8];
-#define WPROF(v) const unsigned long long v = __builtin_readcyclecounter()
-#else
-#define WPROF(v)
-#endif
 
 // locate_chunk by one wave: lane k reads the bounds of offset k, the chunk counts are scanned across the lanes -- one
 // memory latency instead of up to K dependent ones (measured: 6 us of a 25 us launch at the coarse levels)
@@ -203,7 +194,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int c0 = blockIdx.y * 32 * CT, n0 = blockIdx.z * 32 * NT;
-  WPROF(w_t0);
   if (t == 0) {
     locate_chunk(a.offs, a.mpk, a.M, a.chunk, blockIdx.x, s_desc);
     s_desc[5] = blockIdx.x;  // slab of this chunk
@@ -220,9 +210,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[ct][nt][j] = 0.f;
 
-#if PCMI_ABLATE == 9
-  unsigned long long w_t1 = 0, w_groups = 0;
-#endif
   if constexpr (BUF) {
     // Both operands through raw buffer loads with 32-bit byte offsets: the offset of a pair's row is computed once per
     // 64-pair group (one multiply per lane), a pair past the end of the chunk gets an out-of-range offset and reads
@@ -253,13 +240,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     int64_t g0 = pb + (int64_t)wave * 64;
     uint32_t ox = 0, og = 0, oxn = 0, ogn = 0;
     bool primed = false;
-#if PCMI_ABLATE == 9
-    w_t1 = __builtin_readcyclecounter();
-#endif
     for (; g0 < pe; g0 += 256) {
-#if PCMI_ABLATE == 9
-      ++w_groups;
-#endif
       const bool next = g0 + 256 < pe;
       if (!primed) {
         load_off(g0, ox, og);
@@ -311,13 +292,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     int64_t g0 = pb + (int64_t)wave * 64;
     int32_t rx = 0, rg = 0, rxn = 0, rgn = 0;
     bool primed = false;  // ring holds steps 0..D-1 of the group at g0
-#if PCMI_ABLATE == 9
-    w_t1 = __builtin_readcyclecounter();
-#endif
     for (; g0 + 64 <= pe; g0 += 256) {
-  #if PCMI_ABLATE == 9
-      ++w_groups;
-  #endif
       const bool next_full = g0 + 256 + 64 <= pe;
       if (!primed) {
         load_idx(g0, rx, rg);
@@ -375,7 +350,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
     }
 
   }
-  WPROF(w_t2);
   // reduce the 4 waves one after the other through ONE LDS tile, wave 0 writes the slab
   for (int src = 1; src < 4; ++src) {
     if (wave == src) {
@@ -440,20 +414,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < EPT; ++j) base[el[j]] = v[j];
-#if PCMI_ABLATE == 9
-  if (lane == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024) {
-    unsigned long long* o = g_wgrad_prof + ((size_t)blockIdx.x * 4 + wave) * 8;
-    const unsigned long long w_t3 = __builtin_readcyclecounter();
-    o[0] = w_t3 - w_t0;
-    o[1] = w_t1 - w_t0;
-    o[2] = w_t2 - w_t1;
-    o[3] = w_t3 - w_t2;
-    o[4] = w_groups;
-    o[5] = __builtin_amdgcn_s_getreg(63492);
-    o[6] = __builtin_amdgcn_s_getreg(63508);
-    o[7] = (unsigned long long)(pe - pb);
-  }
-#endif
   if (a.mode != kArrive) return;
   // ---- the last workgroup of this (offset, tile) to arrive sums the slabs in chunk order -------------------------
   const int64_t first = s_desc[3], count = s_desc[4];
@@ -650,17 +610,10 @@ static int tiles_per_wg(int tiles32) {  // tiles (of 32 channels) a workgroup co
 // rounds" -- on the level-1 96->96 gradient: 3200 pairs = 12.5 groups per wave, i.e. half the waves of every workgroup
 // waited one whole group (8 % of the loop) at the reduction barrier, and 480 workgroups on 512 slots.
 constexpr int kWgradMinChunk = 256, kWgradMaxChunks = 4096;
-// PCMI_WGRAD_MAX_CHUNK: longest chunk (pairs).  A workgroup of the level-1 gradients runs ~80 us per 1024 pairs and is
-// never pre-empted: while it holds its CU, the latency-critical kernels of the bwd-data chain (higher stream priority,
-// but priority only orders the DISPATCH of new workgroups) wait for a slot.
-static int wgrad_max_chunk() {
-  static const int v = [] {
-    const char* e = getenv("PCMI_WGRAD_MAX_CHUNK");
-    const int c = e ? atoi(e) : 4096;
-    return std::max(256, c / 128 * 128);
-  }();
-  return v;
-}
+// Longest chunk (pairs).  A workgroup of the level-1 gradients runs ~80 us per 1024 pairs and is never pre-empted: while
+// it holds its CU, the latency-critical kernels of the bwd-data chain (higher stream priority, but priority only orders
+// the DISPATCH of new workgroups) wait for a slot.
+static int wgrad_max_chunk() { return 4096; }
 
 static int wgrad_min_chunk(int64_t M) {
   return (int)std::max<int64_t>(kWgradMinChunk, align_up((size_t)ceil_div(M, kWgradMaxChunks), 128));
@@ -788,15 +741,8 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   a.mpk = map ? (int)ceil_div(wgrad_offset_bound(n_in, n_out), a.chunk) : 0;
   const int64_t nchunks = map ? (int64_t)K * a.mpk : ceil_div(M, a.chunk);
   const int64_t max_per_k = map ? a.mpk : nchunks;  // bound of the chunks of one offset
-  static const int arrive_max = [] {  // PCMI_WGRAD_ARRIVE_MAX: most chunks per offset the in-kernel reduction takes
-    const char* e = getenv("PCMI_WGRAD_ARRIVE_MAX");
-    return e ? atoi(e) : 8;
-  }();
-  static const bool direct_ok = [] {  // PCMI_WGRAD_DIRECT=0: always go through slabs (A/B, debugging)
-    const char* e = getenv("PCMI_WGRAD_DIRECT");
-    return !(e && e[0] == '0');
-  }();
-  a.mode = stem ? kSlabs : (max_per_k <= 1 && direct_ok ? kDirect : (max_per_k <= arrive_max ? kArrive : kSlabs));
+  constexpr int kArriveMax = 8;  // most chunks per offset the in-kernel (last-arriver) reduction takes
+  a.mode = stem ? kSlabs : (max_per_k <= 1 ? kDirect : (max_per_k <= kArriveMax ? kArrive : kSlabs));
   a.gw = gweight;
   a.accumulate = accumulate;
   a.counters = nullptr;
@@ -855,11 +801,6 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
 
 extern "C" {
 
-#if PCMI_ABLATE == 9
-int pcmi_debug_wgrad_prof(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wgrad_prof), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? PCMI_OK : PCMI_ERR_HIP;
-}
-#endif
 
 int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
                            int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,

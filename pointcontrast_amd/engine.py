@@ -270,17 +270,6 @@ class NativeEngine:
                                   None, cur_stream(d.device)))
     self._held[pass_id] = None
 
-  def backward_pair(self, d_out0, d_out1, reducer=None):
-    """backward(1, d_out1) and backward(0, d_out0, reducer) enqueued next to each other (two chain streams + the
-    weight-gradient stream); flat.g ends up with the same sums in the same order."""
-    assert self._held[0] is not None and self._held[1] is not None, "forward both passes in training mode first"
-    d = [t if (t.stride(1) == 1 and t.stride(0) % 4 == 0) else t.contiguous() for t in (d_out0, d_out1)]
-    cb, lo_arr, nb = self._ready_args(reducer)
-    with torch.cuda.device(d[0].device):
-      check(lib.pcmi_net_backward_pair(self._h, ptr(d[0]), d[0].stride(0), ptr(d[1]), d[1].stride(0), ptr(self.flat.w),
-                                       ptr(self.flat.g), lo_arr, nb, cb, None, cur_stream(d[0].device)))
-    self._held[0] = self._held[1] = None
-
   @staticmethod
   def _ready_args(reducer):
     cb, lo_arr, nb = READY_FN(), None, 0

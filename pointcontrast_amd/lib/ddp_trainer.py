@@ -311,11 +311,8 @@ class ContrastiveLossTrainer:
       self._feats = None
     elif self.engine is not None:
       F0, F1 = self._feats
-      if self.config.misc.get("concurrent_backward", False):
-        self.engine.backward_pair(F0.grad, F1.grad, reducer=self.reducer)  # buckets final once both passes are in
-      else:
-        self.engine.backward(1, F1.grad)
-        self.engine.backward(0, F0.grad, reducer=self.reducer)  # last pass: buckets become final -> RCCL
+      self.engine.backward(1, F1.grad)
+      self.engine.backward(0, F0.grad, reducer=self.reducer)  # last pass: buckets become final -> RCCL
       self._feats = None
     self.reducer.finish()
     if self.world_size > 1 or self.reducer.active:

@@ -27,6 +27,23 @@ def test_voxelize_and_match_are_bit_exact(seed, crop, voxel):
   assert len(got) > 100 and (np.diff(got[:, 0]) >= 0).all()
 
 
+def test_device_resident_item_geometry_matches_the_numpy_form():
+  """pair_geometry_device (the loader stage with its outputs left on the device) = the numpy-in / numpy-out wrappers =
+  the oracle: surviving points, voxel coordinates, correspondences."""
+  from oracle import loader_ref as lf
+  from pointcontrast_amd.lib import device_loader as dl
+  a, b, T = _pair(5, 9.0)
+  voxel, r = 0.025, 1.5 * 0.025
+  out = dl.pair_geometry_device(a, b, T, voxel, r)
+  sa, sb = lf.sparse_quantize_index(a, voxel), lf.sparse_quantize_index(b, voxel)
+  assert out["xyz0"].is_cuda and out["matches"].is_cuda and out["matches"].dtype == torch.int32
+  assert (out["xyz0"].cpu().numpy() == a[sa]).all() and (out["xyz1"].cpu().numpy() == b[sb]).all()
+  assert (out["coords0"].cpu().numpy() == np.floor(a[sa] / voxel).astype(np.int32)).all()
+  assert (out["coords1"].cpu().numpy() == np.floor(b[sb] / voxel).astype(np.int32)).all()
+  want = lf.match_radius(a[sa], T, b[sb], r)
+  assert (out["matches"].cpu().numpy().astype(np.int64) == want).all() and len(want) > 100
+
+
 def test_loader_kernels_edge_cases():
   from oracle import loader_ref as lf
   from pointcontrast_amd._lib import PcmiError

@@ -775,12 +775,7 @@ def test_engine_matches_autograd_path(ME, name, crop, batch):
   for k, v in dev.state_dict().items():
     if "running" in k:
       assert_close(v, rs_after[k], 1e-5, "forward_pair " + k)
-  g_seq = flat.g.clone()  # of the two sequential engine backwards above
-  flat.zero_grad()
-  eng.backward_pair(g[0], g[1])  # both backwards next to each other: same sums in the same order
-  torch.cuda.synchronize()
-  assert torch.equal(flat.g, g_seq), "backward_pair differs from backward(1); backward(0): max |diff| %.3e" % float(
-      (flat.g - g_seq).abs().max())
+  eng._held[0] = eng._held[1] = None
 
 
 @pytest.mark.parametrize("which", ["nce", "hardest"])
@@ -1043,40 +1038,6 @@ def test_conv16_matches_32row_kernel(ME, size, cin, cout, monkeypatch):
   assert_close(res["1"][1], res["0"][1], 1e-5, "16-row backward-data")
 
 
-@pytest.mark.parametrize("size,cin,cout", [("small", 64, 96), ("mid", 128, 32), ("large", 96, 96), ("large", 64, 128)])
-def test_conv16_pipelined_matches_unpipelined(ME, size, cin, cout, monkeypatch):
-  """spconv16p_kernel (next step's buffer loads issued from inside the MFMA stream; PCMI_CONV16_PIPE, default on)
-  against spconv16_kernel: same operands, same accumulation order -> identical bits on whole tiles, forward and
-  backward-data; 1e-5 under the unit-balanced launch (different split points)."""
-  from pointcontrast_amd import functional as PF
-  C = _coords(size)
-  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
-  cm, key = st.coords_man, st.coords_key
-  m = cm.kernel_map(key, key, 3, 1, 3)
-  torch.manual_seed(4)
-  W = (torch.randn(27, cin, cout, device=DEV) / (cin * 27) ** 0.5).requires_grad_(True)
-  b = torch.randn(cout, device=DEV)
-  g = torch.randn(len(C), cout, device=DEV)
-  monkeypatch.setenv("PCMI_CONV16", "1")
-  monkeypatch.setenv("PCMI_CONV16_X3", "0")  # the two fp32-MFMA forms (the split-precision kernel has its own test)
-  for sk in ("16", "0"):
-    monkeypatch.setenv("PCMI_SPCONV_STREAMK", sk)
-    res = {}
-    for mode in ("0", "1"):
-      monkeypatch.setenv("PCMI_CONV16_PIPE", mode)
-      x = torch.randn(len(C), cin, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
-      y = PF.SparseConvFunction.apply(x, W, b, m, False, len(C), cm)
-      y.backward(g)
-      torch.cuda.synchronize()
-      res[mode] = (y.detach().clone(), x.grad.clone())
-    if sk == "0":
-      assert torch.equal(res["1"][0], res["0"][0]), "forward"
-      assert torch.equal(res["1"][1], res["0"][1]), "backward-data"
-    else:  # the unit-balanced launch of the pipelined form cuts its shares at chunk steps, not at offsets: same sums, other grouping
-      assert_close(res["1"][0], res["0"][0], 1e-5, "forward, unit-balanced")
-      assert_close(res["1"][1], res["0"][1], 1e-5, "backward-data, unit-balanced")
-
-
 def _fp64_conv(cm, m, x, W):
   """sum_k x[nbr_k] @ W[k] in float64 on the device (absent neighbours contribute nothing)."""
   nbr = cm.export_map(m)[0].long()
@@ -1089,14 +1050,14 @@ def _fp64_conv(cm, m, x, W):
   return y
 
 
-@pytest.mark.parametrize("dma", ["1", "0"])
+@pytest.mark.parametrize("dma", ["1"])
 @pytest.mark.parametrize("size,cin,cout", [("mid", 64, 64), ("large", 96, 96), ("large", 128, 96), ("large", 64, 128),
                                            ("mid", 256, 256), ("large", 192, 128)])
 def test_conv16_x3_split_precision_matches_fp32(ME, size, cin, cout, dma, monkeypatch):
   """spconv16x_kernel (csrc/spconv_x3.hip, PCMI_CONV16_X3=1: fp32 operands as three bf16 terms each, six
   v_mfma_f32_16x16x32_bf16 per tile instead of eight v_mfma_f32_16x16x4_f32) against the fp32-MFMA kernel and against a
-  float64 contraction: forward and backward-data, whole-tile and unit-balanced launches, weight blocks by global->LDS
-  loads (PCMI_X3_DMA=1) and through registers.  The split form must be as close to float64 as the fp32 kernel is (both
+  float64 contraction: forward and backward-data, whole-tile and unit-balanced launches (weight blocks by global->LDS
+  loads).  The split form must be as close to float64 as the fp32 kernel is (both
   are fp32-round-off class: ~1e-6 of the largest output) -- far inside the north_star's 1e-4."""
   import json
   from pointcontrast_amd import functional as PF
@@ -1115,7 +1076,6 @@ def test_conv16_x3_split_precision_matches_fp32(ME, size, cin, cout, dma, monkey
   mirror = [int(m.mirror[k]) for k in range(27)]
   g64 = _fp64_conv(cm, m, g, W.detach()[mirror].transpose(1, 2))  # gin[i] = sum_k gout[nbr_k(i)] @ W[mirror(k)]^T
   monkeypatch.setenv("PCMI_CONV16", "1")
-  monkeypatch.setenv("PCMI_X3_DMA", dma)
   report = {}
   for sk in ("16", "0"):
     monkeypatch.setenv("PCMI_SPCONV_STREAMK", sk)
