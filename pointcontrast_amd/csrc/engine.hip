@@ -124,16 +124,16 @@ struct pcmi_net {
   std::vector<pcmi::OpPlan> plan;
   int input_tensor = -1, output_tensor = -1, n_levels = 0;
   std::vector<pcmi::PassState> passes;
-  // side[0]: the weight gradients of a backward pass (off the critical path: nothing downstream reads them), with a
-  // workspace of their own; side[1]: the weight pack of a forward pass (x3_prepack).  Both at the lowest priority.
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr};
-  hipEvent_t ev_pack_in = nullptr, ev_pack_done = nullptr;
-  pcmi::DevBuf ws_side[2];
+  // side: the weight gradients of a backward pass (off the critical path: nothing downstream reads them) at the lowest
+  // stream priority, with a workspace of their own
+  hipStream_t side[1] = {nullptr};
+  hipEvent_t ev_main[1] = {nullptr}, ev_side[1] = {nullptr};
+  pcmi::DevBuf ws_side[1];
   // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
   // top of a forward pass (x3_prepack) instead of one pack launch in front of every convolution
   pcmi::DevBuf x3_packs, x3_jobs_dev;
   std::vector<pcmi::X3Prepacked> x3_table;
+  std::vector<int> x3_nts;  // slice width per (conv op, orientation) the table was built for
   const float* x3_params = nullptr;
   bool x3_current = false;  // the last forward pass packed (the packs are those of its weights)
   int x3_n_jobs = 0;
@@ -141,13 +141,11 @@ struct pcmi_net {
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
   ~pcmi_net() {
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 1; ++i) {
       if (side[i]) (void)hipStreamDestroy(side[i]);
       if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
       if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
     }
-    if (ev_pack_in) (void)hipEventDestroy(ev_pack_in);
-    if (ev_pack_done) (void)hipEventDestroy(ev_pack_done);
   }
 };
 
@@ -199,7 +197,7 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
 // both sides), forward and backward-data orientation, in one launch on `st`, and makes the table current for this
 // thread's convolution calls.  The job table is built once per parameter buffer.  PCMI_X3_PREPACK=0: every convolution
 // packs its own weights in front of its launch (as the C-ABI entry points do).
-static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st) {
+static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st, const std::vector<int64_t>& rows) {
   const char* pe = getenv("PCMI_X3_PREPACK");  // read per pass: the parity test runs both forms in one process
   const bool enabled = !(pe && pe[0] == '0');
   n.x3_current = false;
@@ -207,7 +205,20 @@ static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st) {
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
   }
-  if (n.x3_params != params) {
+  // slice width of every (layer, orientation) for THIS pass's level sizes (a level that crosses a size class between two
+  // batches changes it): the job table is rebuilt when the parameter buffer or any width changes
+  std::vector<int> nts;
+  for (const auto& op : n.ops) {
+    if (op.type != PCMI_OP_CONV || op.kernel_size <= 1) continue;
+    const int K = op.kernel_size * op.kernel_size * op.kernel_size;
+    for (int tr = 0; tr < 2; ++tr) {
+      const int C = tr ? op.cout : op.cin, N = tr ? op.cin : op.cout;
+      nts.push_back(x3_plan_nt(rows[n.tensors[tr ? op.in : op.out].level], C, N, K));
+    }
+  }
+  if (n.x3_params != params || nts != n.x3_nts) {
+    n.x3_nts = nts;
+    size_t slot = 0;
     std::vector<X3PackJob> jobs;
     n.x3_table.clear();
     size_t bytes = 0;
@@ -217,8 +228,7 @@ static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st) {
       const int K = op.kernel_size * op.kernel_size * op.kernel_size;
       for (int tr = 0; tr < 2; ++tr) {  // 0: B = W[k] ([cin x cout]); 1: B = W[k]^T ([cout x cin])
         const int C = tr ? op.cout : op.cin, N = tr ? op.cin : op.cout;
-        if (C % 32 != 0 || N % 32 != 0 || C < 64 || N < 64) continue;
-        const int NT = x3_nt_for(N);
+        const int NT = nts[slot++];
         if (NT < 2) continue;
         X3PackJob j;
         j.w = params + op.w_off;
@@ -298,13 +308,11 @@ static int ensure_streams(pcmi_net& n) {
   // 16.6 ms per iteration; weight gradients on the chain's own stream: 28 ms)
   int least = 0, greatest = 0;
   PCMI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  for (int i = 0; i < 2; ++i) {  // [0]: weight gradients; [1]: the weight pack of a forward pass
+  for (int i = 0; i < 1; ++i) {
     PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, least));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
   }
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_pack_in, hipEventDisableTiming));
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_pack_done, hipEventDisableTiming));
   return PCMI_OK;
 }
 
@@ -536,7 +544,7 @@ int pcmi_net_destroy(pcmi_net_t* net) {
 
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
-  size_t b = net->ws_side[0].cap + net->ws_side[1].cap;
+  size_t b = net->ws_side[0].cap;
   for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap;
   *bytes = b;
   return PCMI_OK;
@@ -648,27 +656,9 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.out_feats = out_feats;
   ps.out_ld = out_ld;
   ps.coords = coords;
-  // The weight pack (0.2 ms for Res16UNet34C) leaves the chain: pass 0 packs on the executor's second side stream, behind
-  // whatever `st` holds now (the optimiser step that produced these weights), and `st` waits for it in front of the first
-  // convolution that can use a pack -- by then the stem and the 32-channel layers have run.  PCMI_X3_PACK_ASYNC=0 / other
-  // passes: packed in line.
-  static const bool pack_async_on = [] {
-    const char* e = getenv("PCMI_X3_PACK_ASYNC");
-    return !(e && e[0] == '0');
-  }();
-  bool pack_pending = false;
-  if (pack_async_on && pass == 0) {
-    rc = ensure_streams(n);
-    if (rc) return rc;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_pack_in, st));
-    PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[1], n.ev_pack_in, 0));
-    rc = x3_prepack(n, params, n.side[1]);
-    if (rc) return rc;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_pack_done, n.side[1]));
-    pack_pending = n.x3_current;
-  } else {
-    rc = x3_prepack(n, params, st);
-  }
+  // (the pack on a side stream, joined in front of the first convolution that needs it, was measured: 237.7 against
+  //  238.3 pairs/s in line -- profiles/r03c_bench_ab.txt -- and is gone)
+  rc = x3_prepack(n, params, st, ps.rows);
   const X3TableScope x3_scope;  // the table is this thread's only until the pass has been enqueued
   if (rc) return rc;
   g_prof_fwd.lap(2);
@@ -678,10 +668,6 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
     if (op.type == PCMI_OP_CONV) {
-      if (pack_pending && op.kernel_size > 1 && op.cin >= 64 && op.cout >= 64) {
-        PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_pack_done, 0));
-        pack_pending = false;
-      }
       rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
                           op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, ps.ws.p, ps.ws.cap,
                           st);
@@ -717,7 +703,6 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     if (rc) return rc;
     g_prof_fwd.lap(op.type == PCMI_OP_CONV ? 3 : (op.type == PCMI_OP_BN ? 4 : 5));
   }
-  if (pack_pending) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_pack_done, 0));  // (no layer used a pack: the backward pass may)
   if ((defer || two_seg) && ps.upd_n > 0) {
     PCMI_HIP_CHECK(hipMemcpyAsync(ps.upd_dev, ps.upd_host, sizeof(BnRunningUpdate) * ps.upd_n, hipMemcpyHostToDevice, st));
     PCMI_HIP_CHECK(hipEventRecord(ps.upd_copied, st));

@@ -847,9 +847,12 @@ static size_t sk_partial_bytes(int64_t rows, int N, int K) {
 // The 16-row kernel takes the 128-row tiles of levels with at least PCMI_CONV16 rows (default 8192; 0 = never, 1 =
 // always).  Measured (scripts/kbench.py): level 2 (20k rows) 3-5 % faster, level 1 equal, the <= 5k-row levels
 // 3-9 % slower (their NT = 1 / offset-split launches are latency-, not matrix-bound).
-static bool conv16_enabled(int64_t n_rows, int64_t x_bytes) {
+static int64_t conv16_min_rows() {
   const char* e = getenv("PCMI_CONV16");
-  const int64_t min_rows = e ? atoll(e) : 8192;
+  return e ? atoll(e) : 8192;
+}
+static bool conv16_enabled(int64_t n_rows, int64_t x_bytes) {
+  const int64_t min_rows = conv16_min_rows();
   // the pipelined form addresses the gathered operand with 32-bit byte offsets (absent = 2^31)
   return min_rows > 0 && n_rows >= min_rows && x_bytes <= 0x7FFFFF00ll;
 }
@@ -934,7 +937,9 @@ constexpr int kMaxKSplit = 27;
 // tiles multiply the weight traffic: measured 10-20 TFLOP/s with 32-row tiles on the 256-channel
 // levels); the parallelism the small levels lack comes from splitting the offset range over
 // blockIdx.z into partial sums instead.
-static Plan make_plan(int64_t rows, int N, int K, bool pair) {
+// wide: the contraction has >= 64 channels (with N >= 64 the launch can take the split-precision kernel, whose slices
+// are at least 64 wide)
+static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false) {
   Plan p;
   const int nt_all = N / 32;
   p.NT = nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
@@ -943,8 +948,9 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair) {
   if (p.RW == 1 && p.NT > 2) p.NT = (nt_all % 2 == 0) ? 2 : 1;  // the cross-wave reduction lives in LDS
   // small levels: narrow output slices partition the weights (no extra weight traffic) and multiply the
   // number of resident workgroups; the re-gathered rows are L2-resident at these sizes
+  const int64_t min16 = conv16_min_rows();
   if (rows < 2048)
-    p.NT = 1;
+    p.NT = (wide && !pair && K > 1 && N >= 64 && nt_all % 2 == 0 && conv16_x3_on() && min16 > 0 && rows >= min16 && p.RW == 4) ? 2 : 1;
   else if (rows < 8192 && p.NT > 2)
     p.NT = (nt_all % 2 == 0) ? 2 : 1;
   if (!pair && K > 1) {
@@ -957,8 +963,18 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair) {
 
 static size_t partial_bytes(int64_t rows, int N, int K) {
   if (K <= 1 || rows <= 0 || N % 32 != 0) return 0;
-  const Plan p = make_plan(rows, N, K, false);
-  return p.ksplit > 1 ? (size_t)p.ksplit * rows * N * sizeof(float) : 0;
+  const int ks = std::max(make_plan(rows, N, K, false, false).ksplit, make_plan(rows, N, K, false, true).ksplit);
+  return ks > 1 ? (size_t)ks * rows * N * sizeof(float) : 0;
+}
+
+// Output slice width (units of 32 channels) of the table launch over `rows` output rows if it takes the split-precision
+// kernel, else 0: what the executor packs the weights for ahead of the launches (engine.hip: x3_prepack).
+int x3_plan_nt(int64_t rows, int C, int N, int K) {
+  if (C % 32 != 0 || N % 32 != 0 || C < 64 || N < 64 || K <= 1 || !conv16_x3_on()) return 0;
+  const Plan p = make_plan(rows, N, K, false, true);
+  const int64_t min16 = conv16_min_rows();
+  if (p.RW != 4 || min16 <= 0 || rows < min16) return 0;
+  return conv16_x3(p.NT, C, N) ? p.NT : 0;
 }
 
 // One gathered GEMM:  out[rows, N] = sum_k x[idx_k(rows)] @ B_k
@@ -1028,7 +1044,7 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     a.nbr = map->nbr_perm;
     a.perm = map->perm;
   }
-  Plan p = make_plan(n_rows, N, a.K, false);
+  Plan p = make_plan(n_rows, N, a.K, false, C >= 64);
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   // (the unit-balanced launch exists for the 16-row kernels: an operand of >= 2 GiB, which they cannot address, takes the
   //  whole-tile launch of spconv_mfma_kernel below)

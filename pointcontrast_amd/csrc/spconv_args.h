@@ -45,6 +45,8 @@ int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st);
 int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st);
 // output slice width (in units of 32 channels) the 128-row launches use for N output channels; < 2: not eligible
 int x3_nt_for(int N);
+// the same for a table launch over `rows` output rows contracting C channels (0: that launch does not take the split kernel)
+int x3_plan_nt(int64_t rows, int C, int N, int K);
 
 // ---- weights packed ahead of the launches (the network executor packs every eligible layer in ONE launch per forward
 // pass instead of one pack launch in front of every convolution) ----------------------------------------------------

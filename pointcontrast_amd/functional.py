@@ -352,9 +352,11 @@ def pairs_scan_host(pos_pairs):
   return n.value, bool(srt.value)
 
 
-def pair_select(pairs_dev, n_unique, uniform_dev, sampled_dev=None):
+def pair_select(pairs_dev, n_unique, uniform_dev, sampled_dev=None, workspace=None):
   """Device side of the PointInfoNCE pair selection (pc/lib/ddp_trainer.py:400-417; pcmi_pair_select): row indices
-  (q_idx into F0, k_idx into F1), int64 [npos] (or [n_unique] without a sub-sample)."""
+  (q_idx into F0, k_idx into F1), int64 [npos] (or [n_unique] without a sub-sample).  Enqueued on torch's current stream;
+  workspace: a caller-owned uint8 tensor (a call on a stream other than the compute stream must not use the shared
+  scratch buffer of the compute-stream ops)."""
   require_cuda(pairs_dev, "pair selection")
   assert pairs_dev.dtype == torch.int32 and pairs_dev.is_contiguous() and uniform_dev.dtype == torch.float32
   assert uniform_dev.numel() == n_unique and (sampled_dev is None or sampled_dev.dtype == torch.int64)
@@ -362,7 +364,12 @@ def pair_select(pairs_dev, n_unique, uniform_dev, sampled_dev=None):
   q = torch.empty(n_sel, dtype=torch.int64, device=pairs_dev.device)
   k = torch.empty(n_sel, dtype=torch.int64, device=pairs_dev.device)
   P = pairs_dev.shape[0]
-  ws, wsb = ws_args(lib.pcmi_pair_select_workspace_bytes(P), pairs_dev.device)
+  need = lib.pcmi_pair_select_workspace_bytes(P)
+  if workspace is not None:
+    assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.numel() >= need
+    ws, wsb = C.c_void_p(workspace.data_ptr()), C.c_size_t(workspace.numel())
+  else:
+    ws, wsb = ws_args(need, pairs_dev.device)
   check(lib.pcmi_pair_select(ptr(pairs_dev), P, n_unique, ptr(uniform_dev), ptr(sampled_dev), n_sel, ptr(q), ptr(k), ws, wsb,
                              cur_stream(pairs_dev.device)))
   return q, k

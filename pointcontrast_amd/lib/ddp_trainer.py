@@ -478,12 +478,14 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     st[slot] = (buf, ev)
     return out
 
-  def select_pairs_device(self, pos_pairs, npos, draws=None, slot=0):
+  def select_pairs_device(self, pos_pairs, npos, draws=None, slot=0, defer_wait=False):
     """select_pairs with the run detection and the gathers on the device (csrc/pairs.hip): the host keeps what consumes
     the random-number streams -- torch.rand(n_unique), np.random.choice(n_unique, npos) -- in the same order as
     select_pairs, plus one native pass over column 0 for n_unique.  Returns device int64 (q_idx, k_idx); bit-identical
     to select_pairs (tests/test_gpu_parity.py::test_device_pair_selection_is_bit_identical).  None: the correspondences
-    are not a sorted contiguous int32 tensor (the caller falls back to the host path)."""
+    are not a sorted contiguous int32 tensor (the caller falls back to the host path).  defer_wait: also returns the event
+    the consumer's stream has to wait for (the selection runs on the planning stream); otherwise the current stream
+    waits for it here."""
     pp = pos_pairs if torch.is_tensor(pos_pairs) else torch.from_numpy(np.asarray(pos_pairs))
     if pp.is_cuda or pp.dtype != torch.int32 or pp.dim() != 2 or not pp.is_contiguous() or pp.shape[0] == 0:
       return None
@@ -498,18 +500,39 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     if npos < nq:
       si = draws["sampled_inds"] if "sampled_inds" in draws else np.random.choice(nq, npos, replace=False)
       si = torch.as_tensor(np.asarray(si)).long()
-    pairs_d = pp.to(self.cur_device, non_blocking=True) if pp.is_pinned() else self._upload_any(pp, ("pairs", slot)).view(pp.shape)
-    u_d = self._upload_any(uniform, ("uniform", slot))
-    si_d = self._upload_any(si, ("sampled", slot)) if si is not None else None
-    return PF.pair_select(pairs_d, nq, u_d, si_d)
+    # Upload + selection go to the planning stream: nothing of it is needed before the loss, and on the compute stream
+    # the 6.7 MB copy of the correspondences sat in front of the forward pass (237.7 against 240.1 pairs/s with the
+    # selection on the host, profiles/r03c_bench_ab.txt).  The compute stream waits for `sel_event` in front of the gathers.
+    from ..runtime import handle_pool
+    from .._lib import lib
+    plan, cur = handle_pool.plan_stream(self.cur_device), torch.cuda.current_stream(self.cur_device)
+    with torch.cuda.stream(plan):
+      pairs_d = pp.to(self.cur_device, non_blocking=True) if pp.is_pinned() else self._upload_any(pp, ("pairs", slot)).view(pp.shape)
+      u_d = self._upload_any(uniform, ("uniform", slot))
+      si_d = self._upload_any(si, ("sampled", slot)) if si is not None else None
+      need = lib.pcmi_pair_select_workspace_bytes(pp.shape[0])
+      wsk = ("pair_ws", slot)
+      ws = getattr(self, "_pair_ws", {}).get(wsk)
+      if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.cur_device)
+        self._pair_ws = dict(getattr(self, "_pair_ws", {}), **{wsk: ws})
+      q_d, k_d = PF.pair_select(pairs_d, nq, u_d, si_d, workspace=ws)
+      ev = torch.cuda.Event()
+      ev.record(plan)
+    for t_ in (q_d, k_d, pairs_d, u_d) + ((si_d,) if si_d is not None else ()):
+      t_.record_stream(cur)
+    if defer_wait:
+      return q_d, k_d, ev
+    cur.wait_event(ev)
+    return q_d, k_d
 
   def _prepare_loss(self, prep, draws):
     slot = getattr(self, "_slot", 0)
     self._slot = slot ^ 2  # two staging buffer pairs: the prefetched batch must not overwrite the live one
     if self.config.misc.get("device_pair_selection", True):
-      sel = self.select_pairs_device(prep["input"]["correspondences"], self.npos, draws, slot)
+      sel = self.select_pairs_device(prep["input"]["correspondences"], self.npos, draws, slot, defer_wait=True)
       if sel is not None:
-        prep["q_idx"], prep["k_idx"] = sel
+        prep["q_idx"], prep["k_idx"], prep["sel_event"] = sel
         return
     q_idx, k_idx = self.select_pairs(prep["input"]["correspondences"], self.npos, draws)
     prep["q_idx"], prep["k_idx"] = self._upload(q_idx, slot), self._upload(k_idx, slot + 1)
@@ -526,6 +549,8 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     mark("next_prepared")
     F0, F1 = self._forward_pair(prep)
     mark("forward")
+    if prep.get("sel_event") is not None:  # the pair selection ran on the planning stream (select_pairs_device)
+      torch.cuda.current_stream(self.cur_device).wait_event(prep["sel_event"])
     q = PF.GatherRowsFunction.apply(F0, prep["q_idx"])
     k = PF.GatherRowsFunction.apply(F1, prep["k_idx"])
     loss = PF.NCELossFunction.apply(q, k, self.T)

@@ -102,6 +102,7 @@ def test_1cm_config_features_and_loss_match_oracle(ME):
                sampled_inds=np.random.RandomState(7).choice(nq, 4096, replace=False))
   prep = trainer._prepare(b, draws)
   F0, F1 = trainer._forward_pair(prep)
+  torch.cuda.current_stream().wait_event(prep["sel_event"])  # the selection runs on the planning stream
   q = PF.GatherRowsFunction.apply(F0, prep["q_idx"])
   k = PF.GatherRowsFunction.apply(F1, prep["k_idx"])
   ld = float(PF.NCELossFunction.apply(q, k, 0.4))
