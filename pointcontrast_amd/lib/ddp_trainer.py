@@ -511,11 +511,12 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
       u_d = self._upload_any(uniform, ("uniform", slot))
       si_d = self._upload_any(si, ("sampled", slot)) if si is not None else None
       need = lib.pcmi_pair_select_workspace_bytes(pp.shape[0])
-      wsk = ("pair_ws", slot)
-      ws = getattr(self, "_pair_ws", {}).get(wsk)
+      ws_cache = getattr(self, "_pair_ws", None)
+      if ws_cache is None:
+        ws_cache = self._pair_ws = {}
+      ws = ws_cache.get(slot)
       if ws is None or ws.numel() < need:
-        ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.cur_device)
-        self._pair_ws = dict(getattr(self, "_pair_ws", {}), **{wsk: ws})
+        ws = ws_cache[slot] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.cur_device)
       q_d, k_d = PF.pair_select(pairs_d, nq, u_d, si_d, workspace=ws)
       ev = torch.cuda.Event()
       ev.record(plan)

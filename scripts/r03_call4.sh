@@ -5,7 +5,7 @@ set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-TAG=${TAG:-r03d}
+TAG=${TAG:-r03e}
 O=gpurun_out/$TAG
 mkdir -p $O
 T0=$(date +%s)
@@ -39,6 +39,6 @@ run "host pair selection" timeout 120 $B --set misc.device_pair_selection=False
 run "conv16 512 + x3t off" PCMI_CONV16=512 PCMI_WGRAD_X3T=0 timeout 120 $B
 stamp "tests with PCMI_CONV16=512"
 PCMI_CONV16=512 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x \
-  -k "network_features or full_config_forward or refsrc or trainer_iteration or joint_pair or engine_matches" > $O/pytest_conv16_512.log 2>&1
-echo "conv16=512 tests exit $?" | tee -a $O/stages.log; grep -E "passed|failed" $O/pytest_conv16_512.log | tail -1; grep -E "^FAILED|^ERROR" $O/pytest_conv16_512.log | head
+  --durations=10 -k "network_features or full_config_forward or refsrc or trainer_iteration or joint_pair or engine_matches" > $O/pytest_conv16_512.log 2>&1
+echo "conv16=512 tests exit $?" | tee -a $O/stages.log; grep -E "passed|failed|s call" $O/pytest_conv16_512.log | tail -12; grep -E "^FAILED|^ERROR" $O/pytest_conv16_512.log | head
 stamp "done"
