@@ -164,7 +164,7 @@ def kernel_rooflines(batch, device, joint=True):
     # which launches the split-precision kernel takes (csrc/spconv.hip: run_gathered): 3^3 / 2^3 table launches of the
     # 16-row kernel with >= 64 channels on both sides -- forward and backward-data, not the weight gradients
     split = (x3_on and mode in ("fwd", "bwd_data") and kmap is not None and min(cin, cout) >= 64 and not transpose
-             and min(n_in, n_out) >= 8192)
+             and min(n_in, n_out) >= int(os.environ.get("PCMI_CONV16", "512")) > 0)
     # ... and the weight gradients of the 3^3 / stride-1 convolutions the tile-stationary kernel takes
     # (csrc/spconv_wgrad_x3.hip: wgrad_x3t_eligible)
     x3t_rows, x3t_max = int(os.environ.get("PCMI_WGRAD_X3T", "16384")), int(os.environ.get("PCMI_WGRAD_X3T_MAX", "100000"))

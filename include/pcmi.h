@@ -185,7 +185,7 @@ int pcmi_spconv_bwd_weight(const float* in, int64_t in_ld, int64_t n_in, int cin
                            const pcmi_kmap_t* map, int transpose, float* gweight,
                            float* gbias /* nullable [cout] */, void* ws, size_t ws_bytes,
                            pcmi_stream_t stream);
-/* 1 if the matrix-bound forward / backward-data launches (>= 64 channels on both sides, >= 8192 rows) run the
+/* 1 if the matrix-bound forward / backward-data launches (>= 64 channels on both sides, >= 512 rows) run the
  * split-precision kernel -- fp32 operands as three bf16 terms each on the bf16 matrix cores, fp32 accumulation,
  * results within fp32 round-off of the fp32-MFMA kernel (csrc/spconv_x3.hip) -- else 0 (environment
  * PCMI_CONV16_X3=0).  The reference has no counterpart: MinkowskiEngine's GEMMs are cuBLAS fp32

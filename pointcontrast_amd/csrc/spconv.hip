@@ -844,12 +844,13 @@ static size_t sk_partial_bytes(int64_t rows, int N, int K) {
   return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups_max() * 2 * 128 * N * sizeof(float) : 0;
 }
 
-// The 16-row kernel takes the 128-row tiles of levels with at least PCMI_CONV16 rows (default 8192; 0 = never, 1 =
-// always).  Measured (scripts/kbench.py): level 2 (20k rows) 3-5 % faster, level 1 equal, the <= 5k-row levels
-// 3-9 % slower (their NT = 1 / offset-split launches are latency-, not matrix-bound).
+// The 16-row kernels take the 128-row tiles of levels with at least PCMI_CONV16 rows (0 = never, 1 = always).  Default
+// 512 since round 3: with the weights of every layer packed for its level's slice width ahead of the launches
+// (x3_plan_nt), the split-precision kernel also wins on the coarse levels -- 240 -> 247 pairs/s at 2048, 249 at 512
+// (profiles/r03e_bench_ab_*.txt); round 2's 8192 was measured with the fp32 form, which lost below it.
 static int64_t conv16_min_rows() {
   const char* e = getenv("PCMI_CONV16");
-  return e ? atoll(e) : 8192;
+  return e ? atoll(e) : 512;
 }
 static bool conv16_enabled(int64_t n_rows, int64_t x_bytes) {
   const int64_t min_rows = conv16_min_rows();
@@ -864,14 +865,6 @@ static bool conv16_x3_on() {
   return !e || atoi(e) != 0;
 }
 static bool conv16_x3(int NT, int C, int N) { return conv16_x3_on() && NT >= 2 && NT <= 4 && C >= 64 && N >= 64; }
-// slice width of the 128-row launches of a level with >= 8192 rows (as make_plan); the executor packs the weights for
-// exactly this width ahead of the launches.  (128-wide outputs as two 64-wide slices -- 3 instead of 2 waves per SIMD --
-// lost stand-alone, 0.186 vs 0.170 ms, and tied in the step: profiles/r02cd_x3_step_ab.txt.)
-int x3_nt_for(int N) {
-  if (N % 32 != 0 || !conv16_x3_on()) return 0;
-  const int nt_all = N / 32;
-  return nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
-}
 // resident workgroups per CU of spconv16x_kernel (LDS: 2 weight blocks of 6 KiB x NT + the 13.5 KiB offset table)
 static int x3_workgroups(int NT) { return (NT <= 3 ? 3 : 2) * num_cu() / 8 * 8; }
 

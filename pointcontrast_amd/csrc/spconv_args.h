@@ -43,9 +43,8 @@ size_t x3_pack_bytes(int K, int C, int N);
 int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st);
 // the 128-row-tile kernel itself (a.wpack set; grid as for spconv16p_kernel); NT in {2, 3, 4}
 int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st);
-// output slice width (in units of 32 channels) the 128-row launches use for N output channels; < 2: not eligible
-int x3_nt_for(int N);
-// the same for a table launch over `rows` output rows contracting C channels (0: that launch does not take the split kernel)
+// output slice width (in units of 32 channels) of a table launch over `rows` output rows contracting C channels
+// (0: that launch does not take the split kernel)
 int x3_plan_nt(int64_t rows, int C, int N, int K);
 
 // ---- weights packed ahead of the launches (the network executor packs every eligible layer in ONE launch per forward

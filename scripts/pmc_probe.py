@@ -26,24 +26,32 @@ m = cm.kernel_map(key, key, 3, 1, 3)
 N = st.F.shape[0]
 
 
-def conv(cin, cout, kmap, K, n_in, n_out):
+def conv(cin, cout, kmap, K, n_in, n_out, modes="fbw", tag=""):
   W = torch.randn((K, cin, cout), device=dev) * 0.05
   x, g = torch.randn(n_in, cin, device=dev), torch.randn(n_out, cout, device=dev)
   yy, gin, gw = torch.empty(n_out, cout, device=dev), torch.empty(n_in, cin, device=dev), torch.empty_like(W)
   ws, wsb = ws_args(lib.pcmi_spconv_workspace_bytes(n_in, n_out, cin, cout, K, kmap.M), dev)
   s = cur_stream(dev)
   for _ in range(REP):
-    check(lib.pcmi_spconv_fwd(ptr(x), cin, n_in, cin, ptr(W), cout, C.byref(kmap), 0, None, ptr(yy), cout, n_out, ws, wsb, s))
-    check(lib.pcmi_spconv_bwd_data(ptr(g), cout, n_out, cout, ptr(W), cin, C.byref(kmap), 0, ptr(gin), cin, n_in, ws, wsb, s))
-    check(lib.pcmi_spconv_bwd_weight(ptr(x), cin, n_in, cin, ptr(g), cout, n_out, cout, C.byref(kmap), 0, ptr(gw), None, ws, wsb, s))
+    if "f" in modes:
+      check(lib.pcmi_spconv_fwd(ptr(x), cin, n_in, cin, ptr(W), cout, C.byref(kmap), 0, None, ptr(yy), cout, n_out, ws, wsb, s))
+    if "b" in modes:
+      check(lib.pcmi_spconv_bwd_data(ptr(g), cout, n_out, cout, ptr(W), cin, C.byref(kmap), 0, ptr(gin), cin, n_in, ws, wsb, s))
+    if "w" in modes:
+      check(lib.pcmi_spconv_bwd_weight(ptr(x), cin, n_in, cin, ptr(g), cout, n_out, cout, C.byref(kmap), 0, ptr(gw), None, ws, wsb, s))
   M = kmap.M
-  print("ALGO conv %d->%d K=%d pairs=%d fwd_bytes=%d bwd_bytes=%d wgrad_bytes=%d flops=%d" %
-        (cin, cout, K, M, M * (4 * cin + 8) + n_out * 4 * cout + 4 * K * cin * cout,
+  print("ALGO conv %s%d->%d K=%d pairs=%d fwd_bytes=%d bwd_bytes=%d wgrad_bytes=%d flops=%d" %
+        (tag, cin, cout, K, M, M * (4 * cin + 8) + n_out * 4 * cout + 4 * K * cin * cout,
          M * (4 * cout + 8) + n_in * 4 * cin + 4 * K * cin * cout, M * 4 * (cin + cout) + 8 * M + 4 * K * cin * cout,
          2 * M * cin * cout))
 
 
 conv(96, 96, m, 27, N, N)
+# the stride-2 level (~40k rows): its weight gradients take the tile-stationary split-precision kernel (wgrad_x3t_kernel)
+ck = cm.stride(key, 2)
+m1 = cm.kernel_map(ck, ck, 3, 1, 3)
+print("LEVEL2 rows=%d pairs=%d" % (cm.size(ck), m1.M))
+conv(96, 96, m1, 27, cm.size(ck), cm.size(ck), modes="w", tag="level2:")  # (only the gradient: fwd / bwd share kernel names with level 1)
 if os.environ.get("PMC_PROBE_ONLY") != "96":
   conv(32, 32, m, 27, N, N)
 torch.cuda.synchronize()

@@ -36,7 +36,7 @@ for line in open(os.path.join(src, "pmc_FETCH_SIZE.log")):
     algo[line.split()[2]] = {k: int(v) for k, v in m.items()}
 rows, traffic = [], {}
 for k in F:
-  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "sk_fixup", "x3_pack", "eltwise_kernel<2>")):
+  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "wgrad_x3t", "wgrad_slab", "sk_fixup", "x3_pack", "eltwise_kernel<2>")):
     continue
   rd = mean(F[k]["FETCH_SIZE"]) * 1024 * f_scale
   wr = mean(W[k]["WRITE_SIZE"]) * 1024 * w_scale if k in W else float("nan")
@@ -59,6 +59,21 @@ for r in rows:
   md.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f %% | %.2f |" % (r[0], r[1], r[2], r[3], r[4], 100 * r[5], r[6]))
 md += ["", "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); issued GFLOP = "
        "(SQ_INSTS_VALU_MFMA_MOPS_F32 + ..._BF16) x 512 (the split-precision kernel issues 6 bf16 products per fp32 product; compare with the algorithmic 2*M*Cin*Cout: the excess is MFMA work on absent neighbours)."]
+# LDS bank conflicts and wave-level stall attribution (optional fourth pass)
+try:
+  L = load("SQ_LDS_BANK_CONFLICT")
+  md += ["", "| kernel | LDS conflict cycles / LDS active cycles | waves: issuing | parked (s_waitcnt / barrier) | issue-stalled (matrix pipe / dependencies) |",
+         "|---|---|---|---|---|"]
+  for k in L:
+    if not any(x in k for x in ("spconv16", "wgrad_mfma", "wgrad_x3t")):
+      continue
+    c = {name: mean(v) for name, v in L[k].items()}
+    wc = max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+    md.append("| `%s` | %.3f | %.1f %% | %.1f %% | %.1f %% |" % (k.split("(")[0], c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
+                                                      100 * c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 100 * c.get("SQ_WAIT_ANY", 0.0) / wc,
+                                                      100 * c.get("SQ_WAIT_INST_ANY", 0.0) / wc))
+except (OSError, KeyError, IndexError) as e:
+  md += ["", "(no LDS / stall pass: %s)" % e]
 open(os.path.join(root, "profiles", "%s_pmc_summary.md" % tag), "w").write("\n".join(md) + "\n")
 json.dump({"source": "%s_pmc_summary.md" % tag, "bytes_per_launch": traffic, "algorithmic": algo},
           open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
