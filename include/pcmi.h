@@ -397,6 +397,12 @@ int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_l
                       const float* params, float* grads, const int64_t* bucket_lo_host,
                       int n_buckets, pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream);
 int pcmi_net_apply_running_stats(pcmi_net_t* net, int pass, pcmi_stream_t stream);
+/* Copy of one activation tensor of the last forward of `pass` (they stay in the pass's arena until its next forward)
+ * into caller memory out [rows, out_ld]; rows / channels (nullable) report its shape, out == NULL only queries.  For
+ * inspection and for tests that hand the device's ReLU patterns to the oracle (the reference has no counterpart: its
+ * activations are autograd-owned torch tensors). */
+int pcmi_net_export_tensor(pcmi_net_t* net, int pass, int tensor, int64_t* rows, int* channels, float* out,
+                           int64_t out_ld, pcmi_stream_t stream);
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes);
 
 #ifdef __cplusplus

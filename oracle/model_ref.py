@@ -77,11 +77,14 @@ class relu_masks:
   zero gets opposite ReLU masks in two implementations and then moves whole gradient tensors by percents -- a
   property of ReLU, not an error of either side.  ``relu_masks(record=lst)`` appends the mask (x > 0) of every
   ReLU call, in call order, to ``lst``; ``relu_masks(apply=lst)`` replaces ReLU by ``x * mask`` with the recorded
-  masks, so that two runs (fp64 / fp32 oracle, device) differentiate exactly the same piecewise-linear function."""
+  masks, so that two runs (fp64 / fp32 oracle, device) differentiate exactly the same piecewise-linear function.
+  ``segment`` ("head" / "tail"): the masks come from a JOINT two-cloud pass of the device (rows of cloud 0 first, then
+  cloud 1, at every level -- NativeEngine.relu_masks) and this forward is cloud 0 / cloud 1: the first / last rows of
+  every mask are used.  ``flips`` / ``total`` count the activations whose own sign disagrees with the imposed mask."""
 
-  def __init__(self, record=None, apply=None):
-    assert (record is None) != (apply is None)
-    self.record, self.apply, self.pos = record, apply, 0
+  def __init__(self, record=None, apply=None, segment=None):
+    assert (record is None) != (apply is None) and segment in (None, "head", "tail")
+    self.record, self.apply, self.pos, self.segment, self.flips, self.total = record, apply, 0, segment, 0, 0
 
   def _fn(self, f):
     if self.record is not None:
@@ -89,7 +92,11 @@ class relu_masks:
       return torch.relu(f)
     m = self.apply[self.pos]
     self.pos += 1
+    if self.segment is not None and m.shape[0] >= f.shape[0] and m.shape[1:] == f.shape[1:]:
+      m = m[:f.shape[0]] if self.segment == "head" else m[m.shape[0] - f.shape[0]:]
     assert m.shape == f.shape, "ReLU call %d: mask %s vs activation %s" % (self.pos - 1, tuple(m.shape), tuple(f.shape))
+    self.flips += int(((f > 0) != m).sum())
+    self.total += m.numel()
     return f * m.to(f.dtype)
 
   def __enter__(self):

@@ -542,6 +542,25 @@ int pcmi_net_destroy(pcmi_net_t* net) {
   return PCMI_OK;
 }
 
+int pcmi_net_export_tensor(pcmi_net_t* net, int pass, int tensor, int64_t* rows, int* channels, float* out, int64_t out_ld,
+                           pcmi_stream_t stream) {
+  PCMI_REQUIRE(net && pass >= 0 && pass < (int)net->passes.size() && tensor >= 0 && tensor < (int)net->tensors.size(),
+               PCMI_ERR_INVALID, "net_export_tensor: bad pass / tensor id");
+  const PassState& ps = net->passes[pass];
+  const auto& T = net->tensors[tensor];
+  PCMI_REQUIRE(!ps.rows.empty() && ps.act.p, PCMI_ERR_INVALID, "net_export_tensor: pass %d has not been forwarded", pass);
+  const int64_t n = ps.rows[T.level];
+  if (rows) *rows = n;
+  if (channels) *channels = T.channels;
+  if (!out || n == 0) return PCMI_OK;
+  PCMI_REQUIRE(out_ld >= T.channels, PCMI_ERR_INVALID, "net_export_tensor: out_ld %lld < %d channels", (long long)out_ld, T.channels);
+  const View v = act_view(*net, ps, tensor);
+  PCMI_REQUIRE(v.p, PCMI_ERR_INVALID, "net_export_tensor: tensor %d has no storage in this pass", tensor);
+  PCMI_HIP_CHECK(hipMemcpy2DAsync(out, sizeof(float) * out_ld, v.p, sizeof(float) * v.ld, sizeof(float) * T.channels, (size_t)n,
+                                  hipMemcpyDeviceToDevice, as_stream(stream)));
+  return PCMI_OK;
+}
+
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
   size_t b = net->ws_side[0].cap;

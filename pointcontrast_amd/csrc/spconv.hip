@@ -948,7 +948,11 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false) 
     p.NT = (nt_all % 2 == 0) ? 2 : 1;
   if (!pair && K > 1) {
     const int64_t wgs = ceil_div(rows, 32 * p.RW) * (nt_all / p.NT);
-    const int64_t target = (25 * (int64_t)num_cu()) / 10;  // workgroups aimed at: 2.5 per CU
+    static const int target_x10 = [] {  // (experiment, round 3 call 7) workgroups aimed at, in tenths of a CU count
+      const char* e = getenv("PCMI_KSPLIT_TARGET");
+      return e && atoi(e) > 0 ? atoi(e) : 25;
+    }();
+    const int64_t target = (target_x10 * (int64_t)num_cu()) / 10;
     if (wgs < target) p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
   }
   return p;

@@ -177,6 +177,7 @@ class NativeEngine:
     self.in_channels, self.out_channels, self.n_down = in_channels, prog["out_channels"], prog["n_down"]
     self._bn_modules = prog["bn_modules"]
     self.n_ops, self.n_tensors = len(prog["ops"]), len(prog["tensors"])
+    self._ops = prog["ops"]  # the lowered program (dicts): which op writes which tensor (activation / relu_masks)
     self._h = create_net(prog, n_passes)
     self._held = [None] * n_passes
     self._pair_stream = None
@@ -279,6 +280,22 @@ class NativeEngine:
       nb = len(order)
       cb = READY_FN(lambda _ctx, q: reducer._launch(order[q]))
     return cb, lo_arr, nb
+
+  def activation(self, pass_id, tensor_id):
+    """Copy of activation tensor `tensor_id` of the last forward of pass `pass_id` ([rows, channels], current stream)."""
+    n, c = C.c_int64(), C.c_int()
+    dev = self.flat.w.device
+    with torch.cuda.device(dev):
+      check(lib.pcmi_net_export_tensor(self._h, pass_id, tensor_id, C.byref(n), C.byref(c), None, 0, cur_stream(dev)))
+      out = torch.empty((n.value, c.value), dtype=torch.float32, device=dev)
+      check(lib.pcmi_net_export_tensor(self._h, pass_id, tensor_id, None, None, ptr(out), c.value, cur_stream(dev)))
+    return out
+
+  def relu_masks(self, pass_id):
+    """(y > 0) of every fused BatchNorm(+residual)+ReLU output of the last forward, in program order -- the order of
+    the ReLU calls of the model's forward (a block's norm1, then its `out += residual; relu`).  Tests hand these to the
+    oracle (oracle.model_ref.relu_masks(apply=...)) so that both differentiate the same piecewise-linear function."""
+    return [self.activation(pass_id, o["out"]) > 0 for o in self._ops if o["type"] == OP_BN and o.get("relu")]
 
   def memory_bytes(self):
     b = C.c_size_t()

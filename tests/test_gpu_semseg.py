@@ -139,7 +139,10 @@ def test_segmentation_trainer_steps_match_oracle(tmp_path):
       g["lr"] = lr_now
     res = tr.train_iter(C, F, target)
     opt.zero_grad()
-    logits = ref(sr.SparseTensorRef(F, coords=C.numpy())).F
+    masks = [m.cpu() for m in tr.engine.relu_masks(0)]  # the device's ReLU patterns (see test_trainer_iteration_matches_oracle)
+    with mr.relu_masks(apply=masks) as kinks:
+      logits = ref(sr.SparseTensorRef(F, coords=C.numpy())).F
+    assert kinks.flips <= 1e-4 * kinks.total
     loss = torch.nn.functional.cross_entropy(logits, target, ignore_index=255)
     loss.backward()
     opt.step()
