@@ -167,10 +167,10 @@ def kernel_rooflines(batch, device, joint=True):
              and min(n_in, n_out) >= int(os.environ.get("PCMI_CONV16", "512")) > 0)
     # ... and the weight gradients of the 3^3 / stride-1 convolutions the tile-stationary kernel takes
     # (csrc/spconv_wgrad_x3.hip: wgrad_x3t_eligible)
-    x3t_rows, x3t_max = int(os.environ.get("PCMI_WGRAD_X3T", "16384")), int(os.environ.get("PCMI_WGRAD_X3T_MAX", "100000"))
+    x3t_rows = int(os.environ.get("PCMI_WGRAD_X3T", "16384"))
     tw = lambda c: c % 96 == 0 or c % 64 == 0
     split = split or (mode == "bwd_weight" and kmap is not None and K == 27 and not transpose and min(cin, cout) >= 64
-                      and tw(cin) and tw(cout) and 0 < x3t_rows <= n_out <= x3t_max)
+                      and tw(cin) and tw(cout) and 0 < x3t_rows <= n_out)
     if bound == "mfma" and split:
       # fp32 products from six bf16 MFMAs: the matrix-pipe bound of THIS arithmetic is the dense bf16 peak / 6; the
       # fraction of the fp32 instruction's own peak is given beside it (it can exceed 1: that is the point of the split)
@@ -188,7 +188,7 @@ def kernel_rooflines(batch, device, joint=True):
   kname = "spconv16x (bf16x3 split)" if x3_on else "spconv16p (fp32 MFMA)"
   dominant = conv_entry("%s fwd 3^3 96->96 @level1 (%d rows)" % (kname, n), 96, 96, m, 27, n, n)
   conv_entry("%s bwd_data 3^3 96->96 @level1" % kname, 96, 96, m, 27, n, n, mode="bwd_data")
-  conv_entry("wgrad_mfma (fp32 MFMA, pair lists) 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
+  conv_entry("wgrad_x3t (bf16x3 split, tile-stationary) 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
   conv_entry("%s fwd 3^3 128->96 @level1" % kname, 128, 96, m, 27, n, n)
   ck = cm.stride(key, 2)
   m2 = cm.kernel_map(key, ck, 2, 2, 0)

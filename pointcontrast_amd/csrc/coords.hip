@@ -968,12 +968,8 @@ int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int bl
   hipStream_t st = as_stream(stream);
   pcmi_kmap_t tmp;
   int rc;
-  // ---- levels: one synchronisation for the whole chain (PCMI_PLAN_CHAIN=0: one per level, as pcmi_coords_stride) ----
-  static const bool chain = [] {
-    const char* e = getenv("PCMI_PLAN_CHAIN");
-    return !(e && e[0] == '0');
-  }();
-  if (chain && h->levels.size() == 1 && n_down > 0 && h->maps.empty()) {
+  // ---- levels: one synchronisation for the whole chain (a fresh handle; otherwise level by level, as pcmi_coords_stride) ----
+  if (h->levels.size() == 1 && n_down > 0 && h->maps.empty()) {
     rc = build_level_chain(h, n_down, st);
     if (rc) return rc;
   }

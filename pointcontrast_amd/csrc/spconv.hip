@@ -948,11 +948,9 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false) 
     p.NT = (nt_all % 2 == 0) ? 2 : 1;
   if (!pair && K > 1) {
     const int64_t wgs = ceil_div(rows, 32 * p.RW) * (nt_all / p.NT);
-    static const int target_x10 = [] {  // (experiment, round 3 call 7) workgroups aimed at, in tenths of a CU count
-      const char* e = getenv("PCMI_KSPLIT_TARGET");
-      return e && atoi(e) > 0 ? atoi(e) : 25;
-    }();
-    const int64_t target = (target_x10 * (int64_t)num_cu()) / 10;
+    // workgroups aimed at: 2.5 per CU (measured again under the round-3 default: 1.0 -> 240.3, 1.5 -> 247.0, 2.5 -> 249.1,
+    // 4.0 -> 244.6 pairs/s, profiles/r03h_bench_ab_*.txt)
+    const int64_t target = (25 * (int64_t)num_cu()) / 10;
     if (wgs < target) p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
   }
   return p;

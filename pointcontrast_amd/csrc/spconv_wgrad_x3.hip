@@ -213,27 +213,24 @@ constexpr int kWgradTMaxRB = 128;
 
 static int wgrad_x3t_tw(int c) { return c % 96 == 0 ? 3 : (c % 64 == 0 ? 2 : 0); }  // 16-wide tiles per wave and axis
 
-// PCMI_WGRAD_X3T: minimum number of rows for the tile-stationary split-precision kernel (0 = never; 1 = every size);
-// PCMI_WGRAD_X3T_MAX: maximum.  Read per call: the parity test runs both kernels in one process.
-// Measured on the bench batch (profiles/r03b_kbench_wgrad_x3t_ab.txt, ms per launch, pair-list fp32 kernel -> this one):
+// PCMI_WGRAD_X3T: minimum number of rows for the tile-stationary split-precision kernel (0 = never; 1 = every size).
+// Read per call: the parity test runs both kernels in one process.
+// Measured on the bench batch, ms per launch stand-alone, pair-list fp32 kernel -> this one (profiles/r03b_kbench_*):
 //   40k rows   96->96 0.205 -> 0.139, 128->96 0.253 -> 0.223
 //   175k rows  96->96 0.509 -> 0.514, 128->96 0.732 -> 0.901   (both kernels are bound by the gathered-row traffic there:
 //              2.3 GB at 4.4 TB/s against 1.8 GB at 3.4 TB/s; this one re-stages the G tile once per offset group)
 //   9.9k rows  64->64 0.026 -> 0.048, 128->128 0.073 -> 0.098, 192->128 0.160 -> 0.121
-// hence the default window [16384, 100000] rows.
+// and in the training step, where it shares the chip with the backward chain (profiles/r03i_bench_ab_x3t_window.txt, 3
+// processes each): rows in [16384, 100000] 248.7-250.3 pairs/s, >= 8192 251.4-252.5, >= 16384 **252.0-252.9** -- at 175k
+// rows it is no faster alone but asks a quarter less of the memory system, which the chain's kernels get.
 static int64_t wgrad_x3t_min_rows() {
   const char* e = getenv("PCMI_WGRAD_X3T");
   return e ? (int64_t)atoll(e) : (int64_t)16384;
 }
-static int64_t wgrad_x3t_max_rows() {
-  const char* e = getenv("PCMI_WGRAD_X3T_MAX");
-  return e ? (int64_t)atoll(e) : (int64_t)100000;
-}
 
 bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int cin, int cout, int64_t in_ld, int64_t gout_ld) {
   const int64_t mr = wgrad_x3t_min_rows();
-  return map && map->kernel_size == 3 && map->stride == 1 && mr > 0 && n_out >= mr && n_out <= wgrad_x3t_max_rows() &&
-         n_in == n_out && cin >= 64 && cout >= 64 &&
+  return map && map->kernel_size == 3 && map->stride == 1 && mr > 0 && n_out >= mr && n_in == n_out && cin >= 64 && cout >= 64 &&
          wgrad_x3t_tw(cin) > 0 && wgrad_x3t_tw(cout) > 0 && n_in * in_ld * 4 <= 0x7FFFFF00ll && n_out * gout_ld * 4 <= 0x7FFFFF00ll;
 }
 
@@ -251,7 +248,7 @@ static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz) {
 size_t wgrad_x3t_workspace(int64_t n_rows, int cin, int cout) {
   const int MTW = wgrad_x3t_tw(cin), NTW = wgrad_x3t_tw(cout);
   const int64_t mr = wgrad_x3t_min_rows();
-  if (MTW == 0 || NTW == 0 || mr <= 0 || n_rows < mr || n_rows > wgrad_x3t_max_rows() || cin < 64 || cout < 64) return 0;
+  if (MTW == 0 || NTW == 0 || mr <= 0 || n_rows < mr || cin < 64 || cout < 64) return 0;
   return (size_t)PCMI_MAX_KERNEL_VOLUME * wgrad_x3t_rb(n_rows, cin / (32 * MTW), cout / (32 * NTW)) * cin * cout * sizeof(float);
 }
 

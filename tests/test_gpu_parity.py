@@ -1133,7 +1133,6 @@ def test_wgrad_x3t_split_precision_matches_fp64(ME, size, cin, cout, monkeypatch
     ok = nbr[k] >= 0
     g64[k] = x[nbr[k][ok]].double().t() @ g[ok].double()
   res = {}
-  monkeypatch.setenv("PCMI_WGRAD_X3T_MAX", "100000000")
   for mode in ("0", "1"):
     monkeypatch.setenv("PCMI_WGRAD_X3T", mode)  # 0: the pair-list kernel; 1: the tile-stationary kernel at every size
     Wm = W.clone().requires_grad_(True)

@@ -152,6 +152,6 @@ def test_segmentation_trainer_steps_match_oracle(tmp_path):
   report = sorted(((float((dict(tr.model.named_parameters())[k].detach().cpu() - p.detach()).abs().max()) /
                     max(float(p.detach().abs().max()), 1e-6), k) for k, p in ref.named_parameters()), reverse=True)
   print("worst parameters after the fine-tuning step:", report[:4])
-  assert report[0][0] <= 5e-3  # observed on MI355X: 1.1e-3 (a BatchNorm bias that starts at zero: the error of lr * gradient)
+  assert report[0][0] <= 1e-4  # observed on MI355X with the shared ReLU patterns: 2.7e-6 (1.1e-3 without them)
   miou, ious, hist = tr.evaluate(C, F, target.numpy())
   assert hist.shape == (20, 20) and hist.sum() == int((target != 255).sum()) and 0.0 <= miou <= 100.0
