@@ -308,6 +308,9 @@ static int ensure_streams(pcmi_net& n) {
   // 16.6 ms per iteration; weight gradients on the chain's own stream: 28 ms)
   int least = 0, greatest = 0;
   PCMI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  // (a stream confined to a subset of the compute units -- hipExtStreamCreateWithCUMask, so that the chain's small
+  //  kernels always find free units -- was tried: such a stream cannot be non-blocking and serialises against the
+  //  caller's default stream, 165 against 253 pairs/s with any mask; profiles/r03j_bench_ab_cu_mask.txt)
   for (int i = 0; i < 1; ++i) {
     PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, least));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
