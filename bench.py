@@ -155,6 +155,7 @@ def kernel_rooflines(batch, device, joint=True):
       fn = lambda: check(lib.pcmi_spconv_bwd_weight(ptr(x), cin, n_in, cin, ptr(g), cout, n_out, cout, kref,
                                                     int(transpose), ptr(gw), None, ws, wsb, s))
       byts = M * 4 * (cin + cout) + 8 * M + 4 * K * cin * cout
+    print("[bench] timing %s" % label, file=sys.stderr, flush=True)
     t = time_kernel(fn)
     flops = 2 * M * cin * cout
     intensity = flops / byts
@@ -207,6 +208,7 @@ def kernel_rooflines(batch, device, joint=True):
     qn.grad = kn.grad = None
     PF.NCELossFunction.apply(qn, kn, 0.4).backward()
 
+  print("[bench] timing nce", file=sys.stderr, flush=True)
   t = time_kernel(nce_step)
   fl = 5 * 2 * 4096 * 4096 * 32
   out.append({"kernel": "nce fwd + bwd, n=4096 c=32 (5 tile GEMMs, fp32 VALU)", "ms": round(t * 1e3, 4), "gflop": round(fl * 1e-9, 3),
@@ -216,6 +218,7 @@ def kernel_rooflines(batch, device, joint=True):
   x = torch.randn(n, 96, device=device)
   gam, bet = torch.ones(96, device=device), torch.zeros(96, device=device)
   rm, rv = torch.zeros(96, device=device), torch.ones(96, device=device)
+  print("[bench] timing bn", file=sys.stderr, flush=True)
   t = time_kernel(lambda: PF.BatchNormFunction.apply(x, gam, bet, rm, rv, 0.1, 1e-5, None, True))
   byts = 12 * n * 96
   out.append({"kernel": "bn_fwd_train+relu [n,96] (3 kernels)", "ms": round(t * 1e3, 4), "algo_mb": round(byts * 1e-6, 2),

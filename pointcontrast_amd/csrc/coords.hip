@@ -818,7 +818,8 @@ static int kmap_get_impl(pcmi_coords_t* h, int in_key, int out_key, int kernel_s
     defer_slot = (int)h->pending.size();
     PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kMapSlot0 + (size_t)defer_slot * kMapSlotLen, offs, sizeof(int64_t) * (K + 1),
                                   hipMemcpyDeviceToHost, st));
-    PCMI_HIP_CHECK(hipEventRecord(h->ev_counts, st));
+    // (ev_counts is recorded at the END of this build, behind the mask sort: whoever waits for the counts of a map --
+    //  pcmi_kmap_get does, before it hands the map out -- has then also waited for every table of it)
   } else {
     PCMI_HIP_CHECK(hipMemsetAsync(offs, 0, sizeof(int64_t) * (K + 1), st));
   }
@@ -857,7 +858,14 @@ static int kmap_get_impl(pcmi_coords_t* h, int in_key, int out_key, int kernel_s
   m.pair_out = pair_out;
   m.offs = offs;
   h->maps.push_back({in_key, out_key, kernel_size, stride, region, m});
-  if (defer_slot >= 0) h->pending.push_back({(int)h->maps.size() - 1, defer_slot});
+  if (defer_slot >= 0) {
+    h->pending.push_back({(int)h->maps.size() - 1, defer_slot});
+    // Until round 3 the event sat right behind the copy of the counts, IN FRONT of the mask sort: a per-call map was
+    // handed out while row_mask / radix sort / permute_table / tile_units were still running on the plan stream, and a
+    // convolution launched on the compute stream within ~100 us read perm / nbr_perm / tile_pref half-written (found
+    // as a GPU memory fault in 1 of 12 runs of bench.py's stand-alone kernel timings, profiles/r03m_*).
+    PCMI_HIP_CHECK(hipEventRecord(h->ev_counts, st));
+  }
   if (defer_slot >= 0 && !h->defer_maps) {
     rc = resolve_pending_maps(h);
     if (rc) return rc;
