@@ -193,10 +193,12 @@ def kernel_rooflines(batch, device, joint=True):
   conv_entry("%s fwd 3^3 128->96 @level1" % kname, 128, 96, m, 27, n, n)
   ck = cm.stride(key, 2)
   m2 = cm.kernel_map(key, ck, 2, 2, 0)
-  conv_entry("spconv_mfma fwd 2^3/s2 32->32 (gather)", 32, 32, m2, 8, m2.n_in, m2.n_out)
+  r32 = int(os.environ.get("PCMI_CONV32R", "8192"))  # csrc/spconv32r.hip: conv32r_min_rows
+  k32 = "spconv32r (weights resident in LDS)" if 0 < r32 <= m2.n_out else "spconv16p (128-row tiles)"
+  conv_entry("%s fwd 2^3/s2 32->32 (gather)" % k32, 32, 32, m2, 8, m2.n_in, m2.n_out)
   conv_entry("spconv_mfma pair fwd 2^3/s2^T 96->96 (scatter)", 96, 96, m2, 8, m2.n_out, m2.n_in, transpose=True)
   m1 = cm.kernel_map(ck, ck, 3, 1, 3)
-  conv_entry("spconv_mfma fwd 3^3 32->32 @level2", 32, 32, m1, 27, m2.n_out, m2.n_out)
+  conv_entry("%s fwd 3^3 32->32 @level2 (%d rows)" % (k32, m2.n_out), 32, 32, m1, 27, m2.n_out, m2.n_out)
   conv_entry("wgrad_x3t (bf16x3 split, tile-stationary) 3^3 96->96 @level2 (%d rows)" % m2.n_out, 96, 96, m1, 27, m2.n_out, m2.n_out,
              mode="bwd_weight")
   conv_entry("stem32_fwd 3^3 3->32 @level1 (lane per row)", 3, 32, cm.kernel_map(key, key, 3, 1, 0), 27, n, n)

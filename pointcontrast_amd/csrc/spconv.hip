@@ -1039,6 +1039,8 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
     a.nbr = map->nbr_perm;
     a.perm = map->perm;
   }
+  // 32 -> 32 channels: all weight slices resident in LDS, a wave per 16-row group (spconv32r.hip)
+  if (conv32r_eligible(a, x_rows * x_ld * 4)) return conv32r_launch(w_transposed, a, st);
   Plan p = make_plan(n_rows, N, a.K, false, C >= 64);
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   // (the unit-balanced launch exists for the 16-row kernels: an operand of >= 2 GiB, which they cannot address, takes the

@@ -47,6 +47,10 @@ int x3_launch(int NT, bool sk, const ConvArgs& a, dim3 grid, hipStream_t st);
 // (0: that launch does not take the split kernel)
 int x3_plan_nt(int64_t rows, int C, int N, int K);
 
+// ---- spconv32r.hip: 32 -> 32 channel table convolutions with the weights resident in LDS ---------------------------
+bool conv32r_eligible(const ConvArgs& a, int64_t x_bytes);  // a.nbr / a.perm / a.K / a.n_rows set
+int conv32r_launch(bool w_transposed, const ConvArgs& a, hipStream_t st);
+
 // ---- weights packed ahead of the launches (the network executor packs every eligible layer in ONE launch per forward
 // pass instead of one pack launch in front of every convolution) ----------------------------------------------------
 struct X3PackJob {   // one (layer, orientation): B_k[c][n] = w[k * w_kstride + c * w_sc + n * w_sn]

@@ -1044,10 +1044,44 @@ def test_conv16_matches_32row_kernel(ME, size, cin, cout, monkeypatch):
   assert_close(res["1"][1], res["0"][1], 1e-5, "16-row backward-data")
 
 
+@pytest.mark.parametrize("size,kind", [("small", "k3"), ("mid", "k3"), ("large", "k3"), ("small", "down"), ("large", "down")])
+def test_conv32r_weights_resident_matches_tile_kernel_and_fp64(ME, size, kind, monkeypatch):
+  """spconv32r_kernel (csrc/spconv32r.hip: 32 -> 32 channels, all weight slices resident in LDS, a wave per 16-row
+  group, PCMI_CONV32R = minimum rows) against the 128-row-tile kernels on the same maps and against float64: forward,
+  bias, accumulate-free output, backward-data (3^3: the mirrored slices through the same table)."""
+  from pointcontrast_amd import functional as PF
+  C = _coords(size)
+  st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+  cm, key = st.coords_man, st.coords_key
+  if kind == "k3":
+    m, K, n_out = cm.kernel_map(key, key, 3, 1, 3), 27, len(C)
+  else:
+    ck = cm.stride(key, 2)
+    m = cm.kernel_map(key, ck, 2, 2, 0)
+    K, n_out = 8, m.n_out
+  torch.manual_seed(11)
+  W = (torch.randn(K, 32, 32, device=DEV) / (32 * K) ** 0.5).requires_grad_(True)
+  b = torch.randn(32, device=DEV)
+  g = torch.randn(n_out, 32, device=DEV)
+  res = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("PCMI_CONV32R", mode)
+    x = torch.randn(len(C), 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)).requires_grad_(True)
+    y = PF.SparseConvFunction.apply(x, W, b, m, False, n_out, cm)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res[mode] = (y.detach().clone(), x.grad.clone(), x.detach())
+  monkeypatch.delenv("PCMI_CONV32R")
+  assert_close(res["1"][0], res["0"][0], 1e-5, "weights-resident forward vs tile kernel")
+  assert_close(res["1"][1], res["0"][1], 1e-5, "weights-resident backward-data vs tile kernel")
+  y64 = _fp64_conv(cm, m, res["1"][2], W.detach()) + b.double()
+  assert_close(res["1"][0], y64, 2e-6, "weights-resident forward vs float64")
+
+
 def _fp64_conv(cm, m, x, W):
   """sum_k x[nbr_k] @ W[k] in float64 on the device (absent neighbours contribute nothing)."""
   nbr = cm.export_map(m)[0].long()
-  y = torch.zeros(x.shape[0], W.shape[2], dtype=torch.float64, device=x.device)
+  y = torch.zeros(nbr.shape[1], W.shape[2], dtype=torch.float64, device=x.device)
   xd, Wd = x.double(), W.double()
   for k in range(W.shape[0]):
     idx = nbr[k]
