@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 3, final GPU call: the driver's bench line (roofline + cpu_baseline), rocprofv3 kernel stats of the same loop,
 # the PMC passes of scripts/pmc_probe.py (HBM traffic, MFMA activity, LDS conflicts), 10 consecutive bench processes,
-# the other configurations, the whole GPU suite + smoke.  Env: TAG, SKIP_TESTS=1.
+# the other configurations, the whole GPU suite + smoke.  Env: TAG, SKIP_TESTS=1, SKIP_PMC=1.
 set -u
 ulimit -c 0
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -21,7 +21,7 @@ stamp "2 rocprofv3 kernel stats"
 echo "prof exit $?" >> $O/stages.log
 find $O/prof -name "*kernel_trace*" -size +8M -delete 2>/dev/null
 stamp "3 PMC passes"
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" \
+[ "${SKIP_PMC:-0}" = "1" ] || for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $pass | cut -d" " -f1)
   ( cd /tmp && PMC_PROBE_ONLY=96 timeout 150 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$GRAFT_REPO_ROOT/$O/pmc_$tag" -o pmc -- \
