@@ -1078,6 +1078,28 @@ def test_conv32r_weights_resident_matches_tile_kernel_and_fp64(ME, size, kind, m
   assert_close(res["1"][0], y64, 2e-6, "weights-resident forward vs float64")
 
 
+def test_per_call_kernel_map_is_complete_when_handed_out(ME):
+  """pcmi_kmap_get hands a map out only after ALL of its tables are written: the mask sort of a 3^3 map (perm, nbr_perm,
+  tile units) runs on the plan stream BEHIND the copy of the pair counts the call waits for, and until round 3 a
+  convolution launched on the compute stream right after the call could read them half-written (a GPU memory fault in
+  bench.py's stand-alone kernel timings).  A convolution launched immediately must equal the same launch after a
+  device-wide synchronisation, on fresh maps, many times."""
+  from pointcontrast_amd import functional as PF
+  C = _coords("large")
+  torch.manual_seed(2)
+  W = torch.randn(27, 32, 32, device=DEV) / 30
+  x = torch.randn(len(C), 32, device=DEV)
+  for it in range(12):
+    st = _device_tensor(ME, C, np.zeros((len(C), 4), np.float32))
+    cm, key = st.coords_man, st.coords_key
+    m = cm.kernel_map(key, key, 3, 1, 3)
+    y_now = PF.SparseConvFunction.apply(x, W, None, m, False, len(C), cm)  # no synchronisation in between
+    torch.cuda.synchronize()
+    y_later = PF.SparseConvFunction.apply(x, W, None, m, False, len(C), cm)
+    torch.cuda.synchronize()
+    assert torch.equal(y_now, y_later), "iteration %d: the map was used before it was complete" % it
+
+
 def _fp64_conv(cm, m, x, W):
   """sum_k x[nbr_k] @ W[k] in float64 on the device (absent neighbours contribute nothing)."""
   nbr = cm.export_map(m)[0].long()
