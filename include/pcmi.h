@@ -231,7 +231,8 @@ int pcmi_l2norm_bwd(const float* dy, int64_t dy_ld, const float* y, int64_t y_ld
 
 /* ------------------------------------------------------------------------------------------
  * Row gather / scatter-add used by the losses (F0[q_idx], pc/lib/ddp_trainer.py:209-213,409-410)
- * scatter_add accumulates into dst (caller zero-fills); duplicate indices are summed.
+ * scatter_add accumulates into dst (caller zero-fills); duplicate indices are summed in increasing source-row
+ * order, without float atomics (bit-reproducible; n^2 / 64 wave steps: meant for the losses' n of a few thousand).
  * ------------------------------------------------------------------------------------------ */
 int pcmi_gather_rows(const float* src, int64_t src_ld, const int64_t* idx, int64_t n, int c,
                      float* dst, int64_t dst_ld, pcmi_stream_t stream);

@@ -414,8 +414,7 @@ __global__ __launch_bounds__(256) void hardest_grad_kernel(
     const float* __restrict__ sub1, const float* __restrict__ d01, const int32_t* __restrict__ i01,
     const uint8_t* __restrict__ m0, const float* __restrict__ d10, const int32_t* __restrict__ i10,
     const uint8_t* __restrict__ m1, float pt, float nt, const float* __restrict__ stats,
-    const float* __restrict__ gl, float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ gsub0,
-    float* __restrict__ gsub1) {
+    const float* __restrict__ gl, float* __restrict__ g0, float* __restrict__ g1) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= p * c) return;
   const int64_t i = idx / c;
@@ -440,8 +439,7 @@ __global__ __launch_bounds__(256) void hardest_grad_kernel(
       const int32_t q = i01[i];
       const float coef = up_neg * -2.f * h / stats[2] * 0.5f;  // d neg / d D01
       const float gd = coef * (a - sub1[(int64_t)q * c + d]) / d01[i];
-      ga += gd;
-      atomicAdd(&gsub1[(int64_t)q * c + d], -gd);
+      ga += gd;  // (the matching -gd of the mined row: hardest_gsub_kernel)
     }
   }
   if (m1[i]) {
@@ -451,11 +449,53 @@ __global__ __launch_bounds__(256) void hardest_grad_kernel(
       const float coef = up_neg * -2.f * h / stats[4] * 0.5f;
       const float gd = coef * (b - sub0[(int64_t)q * c + d]) / d10[i];
       gb += gd;
-      atomicAdd(&gsub0[(int64_t)q * c + d], -gd);
     }
   }
   g0[idx] = ga;
   g1[idx] = gb;
+}
+
+// Gradient of the mined negatives, WITHOUT float atomics: several positives may have mined the same row q, and the sum
+// of their contributions must not depend on the order the hardware retires atomics in (the step is bit-reproducible,
+// tests/test_gpu_fullsize.py).  One wave per positive i: it OWNS row q = imin[i] if no earlier active positive mined q,
+// and then adds the contributions of all positives that mined q in increasing i (lane = channel).  p^2 / 64 wave steps
+// over three L1-resident arrays: a few microseconds at p = 4096.
+//   side 0: fpos = f0, sub = sub1 (row q of the other cloud's candidates), dmin / imin / mask = d01 / i01 / m0, den = stats[2]
+__global__ __launch_bounds__(256) void hardest_gsub_kernel(const float* __restrict__ fpos, int64_t p, int c,
+                                                           const float* __restrict__ sub, const float* __restrict__ dmin,
+                                                           const int32_t* __restrict__ imin, const uint8_t* __restrict__ mask,
+                                                           float nt, const float* __restrict__ stats, int den_slot,
+                                                           const float* __restrict__ gl, float* __restrict__ gsub) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= p) return;  // (wave-uniform)
+  auto active = [&](int64_t j) { return j < p && mask[j] && nt - dmin[j] > 0.f; };
+  if (!active(i)) return;
+  const int32_t q = imin[i];
+  bool dup = false;
+  for (int64_t b = 0; b < i; b += 64) {
+    const int64_t j = b + lane;
+    dup |= j < i && active(j) && imin[j] == q;
+  }
+  if (__any(dup)) return;  // an earlier positive owns row q
+  const float up_neg = gl[1], den = stats[den_slot];
+  for (int d0 = 0; d0 < c; d0 += 64) {
+    const int d = d0 + lane;
+    const float sq = d < c ? sub[(int64_t)q * c + d] : 0.f;
+    float sum = 0.f;
+    for (int64_t b = i; b < p; b += 64) {
+      const int64_t j = b + lane;
+      uint64_t m = __ballot(active(j) && imin[j] == q);
+      while (m) {
+        const int64_t jj = b + __builtin_ctzll(m);
+        m &= m - 1;
+        const float h = nt - dmin[jj];
+        const float coef = up_neg * -2.f * h / den * 0.5f;
+        if (d < c) sum -= coef * (fpos[jj * c + d] - sq) / dmin[jj];
+      }
+    }
+    if (d < c) gsub[(int64_t)q * c + d] += sum;
+  }
 }
 
 // ---- rows gather / scatter-add ------------------------------------------------------------------------
@@ -469,13 +509,36 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_ld
       *reinterpret_cast<const float4*>(src + idx[r] * src_ld + col * 4);
 }
 
-__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int64_t src_ld, const int64_t* __restrict__ idx,
-                                        int64_t n, int c, float* __restrict__ dst, int64_t dst_ld) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * c) return;
-  const int64_t r = e / c;
-  const int col = (int)(e - r * c);
-  atomicAdd(dst + idx[r] * dst_ld + col, src[r * src_ld + col]);
+// dst[idx[r]] += src[r] WITHOUT float atomics (idx may repeat: two positives matched to the same row): one wave per source
+// row; it owns dst[idx[r]] if no earlier row has the same index and then adds the rows with that index in increasing r
+// (lane = column).  n^2 / 64 wave steps over the index array (L1-resident at the loss's n = 4096 .. 8192).
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t src_ld,
+                                                               const int64_t* __restrict__ idx, int64_t n, int c,
+                                                               float* __restrict__ dst, int64_t dst_ld) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;  // (wave-uniform)
+  const int64_t target = idx[r];
+  bool dup = false;
+  for (int64_t b = 0; b < r; b += 64) {
+    const int64_t j = b + lane;
+    dup |= j < r && idx[j] == target;
+  }
+  if (__any(dup)) return;
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int col = c0 + lane;
+    float sum = col < c ? src[r * src_ld + col] : 0.f;
+    for (int64_t b = r + 1; b < n; b += 64) {
+      const int64_t j = b + lane;
+      uint64_t m = __ballot(j < n && idx[j] == target);
+      while (m) {
+        const int64_t jj = b + __builtin_ctzll(m);
+        m &= m - 1;
+        if (col < c) sum += src[jj * src_ld + col];
+      }
+    }
+    if (col < c) dst[target * dst_ld + col] += sum;
+  }
 }
 
 // ---- softmax cross-entropy with ignore label (downstream reuse of the backbone) ---------------------------------
@@ -613,7 +676,7 @@ int pcmi_scatter_add_rows(const float* src, int64_t src_ld, const int64_t* idx, 
                           int64_t dst_ld, pcmi_stream_t stream) {
   PCMI_REQUIRE(src && idx && dst && c > 0, PCMI_ERR_INVALID, "scatter_add_rows: bad argument");
   if (n == 0) return PCMI_OK;
-  scatter_add_rows_kernel<<<dim3((unsigned)ceil_div(n * c, 256)), 256, 0, as_stream(stream)>>>(src, src_ld, idx, n, c, dst, dst_ld);
+  scatter_add_rows_kernel<<<dim3((unsigned)ceil_div(n, 4)), 256, 0, as_stream(stream)>>>(src, src_ld, idx, n, c, dst, dst_ld);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -759,9 +822,16 @@ int pcmi_hardest_loss_bwd(const float* posF0, const float* posF1, int64_t p, con
   PCMI_REQUIRE(posF0 && posF1 && subF0 && subF1 && d01min && d01ind && mask0 && d10min && d10ind && mask1 && stats && gl &&
                    dposF0 && dposF1 && dsubF0 && dsubF1 && p > 0 && c > 0,
                PCMI_ERR_INVALID, "hardest_loss_bwd: bad argument");
-  hardest_grad_kernel<<<dim3((unsigned)ceil_div(p * c, 256)), 256, 0, as_stream(stream)>>>(
+  hipStream_t st = as_stream(stream);
+  hardest_grad_kernel<<<dim3((unsigned)ceil_div(p * c, 256)), 256, 0, st>>>(
       posF0, posF1, p, c, subF0, subF1, d01min, d01ind, mask0, d10min, d10ind, mask1, pos_thresh, neg_thresh, stats, gl,
-      dposF0, dposF1, dsubF0, dsubF1);
+      dposF0, dposF1);
+  PCMI_LAUNCH_CHECK();
+  // the mined rows' gradients (+= into the caller's zeroed dsubF1 / dsubF0), in positive order: no float atomics
+  const dim3 gw((unsigned)ceil_div(p, 4));
+  hardest_gsub_kernel<<<gw, 256, 0, st>>>(posF0, p, c, subF1, d01min, d01ind, mask0, neg_thresh, stats, 2, gl, dsubF1);
+  PCMI_LAUNCH_CHECK();
+  hardest_gsub_kernel<<<gw, 256, 0, st>>>(posF1, p, c, subF0, d10min, d10ind, mask1, neg_thresh, stats, 4, gl, dsubF0);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

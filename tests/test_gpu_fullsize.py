@@ -117,3 +117,30 @@ def test_1cm_config_features_and_loss_match_oracle(ME):
   print("1 cm: N0 %d N1 %d loss device %.6f oracle %.6f" % (N0, N1, ld, lref))
   assert abs(ld - lref) <= 1e-4 * abs(lref), (ld, lref)
   trainer.engine._held[0] = None
+
+
+def test_full_config_step_is_bit_reproducible():
+  """configs[1] at full size, twice: two trainers built from the same seed take two PointInfoNCE iterations on the same
+  batch with the same draws -- weights, SGD momentum and losses must be IDENTICAL bit for bit.  Every accumulation of
+  the step has a fixed order (no float atomics: partial tiles / slabs / row-block partials summed in index order, the
+  weight gradients on their own stream included), so concurrency between the compute, plan and weight-gradient streams
+  may change the timing of a step but not one bit of its result."""
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  batch = _torch_batch(synthetic.make_batch(seed=0, batch_size=4, voxel_size=0.025))
+  pp = batch["correspondences"].numpy()
+  nq = len(np.unique(pp[:, 0]))
+  runs = []
+  for _ in range(2):
+    _, trainer, _, loader = _trainer("PointNCELossTrainer", batch, 4)
+    losses = []
+    for step in range(2):
+      draws = dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(step)),
+                   sampled_inds=np.random.RandomState(step).choice(nq, 4096, replace=False))
+      losses.append(float(trainer._train_iter(iter(FixedBatchLoader([batch], 4)), [AverageMeter(), Timer(), Timer()], draws=draws)["loss"]))
+    torch.cuda.synchronize()
+    runs.append((losses, trainer.flat.w.clone(), trainer.flat.v.clone()))
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  assert torch.equal(runs[0][1], runs[1][1]), "weights differ between two identical runs"
+  assert torch.equal(runs[0][2], runs[1][2]), "SGD momentum differs between two identical runs"
