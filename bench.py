@@ -1,8 +1,9 @@
 """Benchmark of the PointContrast pre-training hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-          --master-port P bench.py --gpus N --steps K --warmup W)
+  N > 1 either way: under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+  127.0.0.1 --master-port P bench.py --gpus N ...: RANK / WORLD_SIZE come from the environment), or bare -- without
+  WORLD_SIZE in the environment bench.py starts its N ranks itself (pointcontrast_amd/lib/multiprocessing.py).
 
 Metric (BASELINE.json): scene-pairs/sec of the full training iteration -- 2 forwards of
 Res16UNet34C, PointInfoNCE (or HardestContrastive with --loss hardest), backward, gradient
@@ -315,19 +316,26 @@ def main():
   ap.add_argument("--set", action="append", default=[], metavar="a.b=c", help="extra config override (A/B experiments)")
   args = ap.parse_args()
 
+  import __graft_entry__
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # No external launcher: start the N ranks ourselves, as the reference's entry point does (pc/ddp_train.py:57-59 ->
+    # lib/multiprocessing.py:36-56).  The library is built ONCE, here, before any rank exists; every rank is this same
+    # script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment; a failing rank stops the others and its
+    # exit code becomes ours.  Rank 0 inherits this stdout, so the JSON line arrives where the caller reads it.
+    __graft_entry__.build()
+    from pointcontrast_amd.lib.multiprocessing import launch_script_ranks
+    sys.exit(launch_script_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
   import torch
   import torch.distributed as dist
   assert torch.cuda.is_available(), "bench.py measures the HIP path and needs an MI355X (no CPU fallback)"
-  import __graft_entry__
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
-  if rank == 0:
-    __graft_entry__.build()
+  __graft_entry__.build()  # every rank: an exclusive file lock inside serialises them, all but the first find it built
   from pointcontrast_amd.lib import distributed as du
   if world > 1:
     du.init_process_group()
     dist.barrier()
-  assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+  assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
   device = torch.device("cuda", torch.cuda.current_device())
 
   from pointcontrast_amd.lib.config import get_config

@@ -374,7 +374,11 @@ typedef struct pcmi_net_op {
   float* running_var;
   float momentum, eps;
 } pcmi_net_op_t;
-/* Called from pcmi_net_backward as soon as every gradient of parameter range `bucket` is final. */
+/* Called from pcmi_net_backward as soon as every gradient of parameter range `bucket` has been ENQUEUED -- on the
+ * backward stream and, for the weight gradients, on the executor's own low-priority stream.  The backward chain does not
+ * wait for that stream at a bucket boundary; a consumer (the gradient all-reduce, pc/lib/ddp_trainer.py:96-102 = what
+ * DistributedDataParallel's bucket hooks do) orders ITS stream behind both from inside the callback with
+ * pcmi_net_stream_wait_bucket. */
 typedef void (*pcmi_ready_fn)(void* ctx, int bucket);
 
 int pcmi_net_create(const pcmi_net_tensor_t* tensors, int n_tensors, const pcmi_net_op_t* ops,
@@ -397,6 +401,9 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
 int pcmi_net_backward(pcmi_net_t* net, int pass, const float* d_out, int64_t d_ld,
                       const float* params, float* grads, const int64_t* bucket_lo_host,
                       int n_buckets, pcmi_ready_fn ready, void* ready_ctx, pcmi_stream_t stream);
+/* Inside a pcmi_ready_fn callback: `stream` waits (device side, no host wait) for everything that produced the bucket
+ * the callback announces.  PCMI_ERR_INVALID outside a backward pass that has announced a bucket. */
+int pcmi_net_stream_wait_bucket(pcmi_net_t* net, pcmi_stream_t stream);
 int pcmi_net_apply_running_stats(pcmi_net_t* net, int pass, pcmi_stream_t stream);
 /* Copy of one activation tensor of the last forward of `pass` (they stay in the pass's arena until its next forward)
  * into caller memory out [rows, out_ld]; rows / channels (nullable) report its shape, out == NULL only queries.  For

@@ -133,6 +133,7 @@ PROTOTYPES = {
     "pcmi_net_backward": (C.c_int, [c_vp, C.c_int, c_vp, c_i64, c_vp, c_vp, C.POINTER(c_i64), C.c_int, READY_FN, c_vp,
                                     c_vp]),
     "pcmi_net_apply_running_stats": (C.c_int, [c_vp, C.c_int, c_vp]),
+    "pcmi_net_stream_wait_bucket": (C.c_int, [c_vp, c_vp]),
     "pcmi_net_export_tensor": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(c_i64), C.POINTER(C.c_int), c_vp, c_i64, c_vp]),
     "pcmi_net_memory_bytes": (C.c_int, [c_vp, C.POINTER(c_sz)]),
 }

@@ -36,7 +36,21 @@ def _digest(paths):
 
 
 def build_lib(force=False, verbose=False):
+  """Compiles what changed and links libpcmi.so.  Safe to call from several processes at once (the ranks of a
+  multi-GPU run all call it): an exclusive file lock serialises them, the first one builds, the others find the
+  digests matching; the library is linked under a temporary name and renamed into place, so a process that is
+  loading it never sees a half-written file."""
+  import fcntl
   os.makedirs(BUILD, exist_ok=True)
+  with open(os.path.join(BUILD, ".lock"), "w") as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+      return _build_locked(force, verbose)
+    finally:
+      fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
   headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "spconv_args.h"), os.path.join(CSRC, "x3_split.h"), os.path.join(HERE, "..", "include", "pcmi.h")]
   hipcc = _hipcc()
 
@@ -61,12 +75,16 @@ def build_lib(force=False, verbose=False):
     results = list(ex.map(compile_one, SOURCES))
   objs = [o for o, _ in results]
   if force or any(ch for _, ch in results) or not os.path.exists(LIB):
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs
+    tmp = LIB + ".tmp%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", tmp] + objs
     if verbose:
       print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
+      if os.path.exists(tmp):
+        os.remove(tmp)
       raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    os.replace(tmp, LIB)
   return LIB
 
 

@@ -128,6 +128,10 @@ struct pcmi_net {
   // stream priority, with a workspace of their own
   hipStream_t side[1] = {nullptr};
   hipEvent_t ev_main[1] = {nullptr}, ev_side[1] = {nullptr};
+  // what produced the gradient bucket the running `ready` callback is about: the chain up to the bucket's last op on
+  // the backward stream, and the weight gradients enqueued so far on the side stream (pcmi_net_stream_wait_bucket)
+  hipEvent_t ev_bkt_main = nullptr, ev_bkt_side = nullptr;
+  bool bkt_valid = false, bkt_side = false;
   pcmi::DevBuf ws_side[1];
   // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
   // top of a forward pass (x3_prepack) instead of one pack launch in front of every convolution
@@ -146,6 +150,8 @@ struct pcmi_net {
       if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
       if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
     }
+    if (ev_bkt_main) (void)hipEventDestroy(ev_bkt_main);
+    if (ev_bkt_side) (void)hipEventDestroy(ev_bkt_side);
   }
 };
 
@@ -316,6 +322,8 @@ static int ensure_streams(pcmi_net& n) {
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
   }
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_main, hipEventDisableTiming));
+  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_side, hipEventDisableTiming));
   return PCMI_OK;
 }
 
@@ -334,7 +342,7 @@ struct BackwardRun {
   PassState* ps = nullptr;
   DevBuf* wws = nullptr;
   float* scratch_g = nullptr;
-  bool side_pending = false;
+  bool side_pending = false, side_used = false;
   std::vector<int> bucket_last;
 
   BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
@@ -380,7 +388,8 @@ struct BackwardRun {
     if (rc) return rc;
     wst = n.side[0];
     wws = &n.ws_side[0];
-    side_pending = false;
+    side_pending = side_used = false;
+    n.bkt_valid = false;
     // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
     bucket_last.assign(n_buckets, -1);
     for (int i = n_ops - 1; i >= 0 && n_buckets > 0; --i) {
@@ -406,7 +415,7 @@ struct BackwardRun {
       // dy is complete at this point of `st` (all its consumers were differentiated before)
       PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
       PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[0], 0));
-      side_pending = true;
+      side_pending = side_used = true;
       rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose, grads + op.w_off,
                                   op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
       if (rc) return rc;
@@ -435,16 +444,25 @@ struct BackwardRun {
                            (pcmi_stream_t)st);
     }
     if (rc) return rc;
+    // A bucket is final once this op's kernels have run -- on `st` AND, for the weight gradients, on the side stream.
+    // The chain does NOT wait for the side stream here (round 3 joined the two at every bucket boundary: with five
+    // buckets the backward chain stalled five times per step behind a weight-gradient stream that runs behind it by
+    // design -- and only when a reducer was attached, so the 1-GPU step did not predict the per-GPU step at N > 1).
+    // Both positions are recorded as events instead and the consumer orders ITS stream behind them from inside the
+    // callback (pcmi_net_stream_wait_bucket); the one join of the pass stays in end(), in front of the optimiser.
     for (int b = 0; b < n_buckets; ++b)
-      if (bucket_last[b] == i) {
-        rc = join_side();
-        if (rc) return rc;
-        if (ready) ready(ready_ctx, b);
+      if (bucket_last[b] == i && ready) {
+        PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_main, st));
+        if (side_used) PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_side, wst));
+        n.bkt_side = side_used;
+        n.bkt_valid = true;
+        ready(ready_ctx, b);
       }
     return PCMI_OK;
   }
 
   int end() {
+    n.bkt_valid = false;
     const int rc = join_side();
     if (rc) return rc;
     ps->valid = false;
@@ -738,6 +756,14 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   static const char* const kFwdNames[] = {"levels", "maps", "layout+reserve", "conv", "bn", "l2norm", "tail"};
   g_prof_fwd.report("net_forward", kFwdNames, 7);
   ps.valid = train;
+  return PCMI_OK;
+}
+
+int pcmi_net_stream_wait_bucket(pcmi_net_t* net, pcmi_stream_t stream) {
+  PCMI_REQUIRE(net, PCMI_ERR_INVALID, "net_stream_wait_bucket: null argument");
+  PCMI_REQUIRE(net->bkt_valid, PCMI_ERR_INVALID, "net_stream_wait_bucket: only valid inside a pcmi_ready_fn callback");
+  PCMI_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), net->ev_bkt_main, 0));
+  if (net->bkt_side) PCMI_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), net->ev_bkt_side, 0));
   return PCMI_OK;
 }
 

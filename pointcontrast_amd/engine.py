@@ -265,20 +265,28 @@ class NativeEngine:
     only on the LAST backward of the iteration."""
     assert self._held[pass_id] is not None, "forward(training=True) first"
     d = d_out if (d_out.stride(1) == 1 and d_out.stride(0) % 4 == 0) else d_out.contiguous()
-    cb, lo_arr, nb = self._ready_args(reducer)
+    cb, lo_arr, nb = self._ready_args(reducer, self._wait_bucket)
     with torch.cuda.device(d.device):
       check(lib.pcmi_net_backward(self._h, pass_id, ptr(d), d.stride(0), ptr(self.flat.w), ptr(self.flat.g), lo_arr, nb, cb,
                                   None, cur_stream(d.device)))
     self._held[pass_id] = None
 
+  def _wait_bucket(self, stream):
+    """Inside a bucket-ready callback: `stream` (the reducer's communication stream) waits for the chain AND the
+    executor's weight-gradient stream up to the bucket -- the backward chain itself does not join them there."""
+    check(lib.pcmi_net_stream_wait_bucket(self._h, C.c_void_p(stream.cuda_stream)))
+
   @staticmethod
-  def _ready_args(reducer):
+  def _ready_args(reducer, wait_bucket=None):
     cb, lo_arr, nb = READY_FN(), None, 0
     if reducer is not None and reducer.active:
       order = sorted(range(len(reducer.buckets)), key=lambda b: reducer.buckets[b][0])
       lo_arr = (C.c_int64 * len(order))(*[reducer.buckets[b][0] for b in order])
       nb = len(order)
-      cb = READY_FN(lambda _ctx, q: reducer._launch(order[q]))
+      if wait_bucket is None:  # (tests drive the callback with CPU stand-ins for the executor)
+        cb = READY_FN(lambda _ctx, q: reducer._launch(order[q]))
+      else:
+        cb = READY_FN(lambda _ctx, q: reducer._launch(order[q], order_behind=wait_bucket))
     return cb, lo_arr, nb
 
   def activation(self, pass_id, tensor_id):

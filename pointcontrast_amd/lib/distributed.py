@@ -132,8 +132,11 @@ class GradReducer:
         self._launch(b)
     return hook
 
-  def _launch(self, b):
-    """All-reduce bucket b now (autograd hook, or the native engine's ready callback)."""
+  def _launch(self, b, order_behind=None):
+    """All-reduce bucket b now (autograd hook, or the native engine's ready callback).  order_behind(stream): the
+    producer's own way of ordering a stream behind the bucket's gradients (the native executor writes them on two
+    streams and joins neither to the other at a bucket boundary: NativeEngine._wait_bucket); without it the
+    communication stream waits for the current stream's position, as a DDP bucket hook does."""
     if not self.active or self._launched[b]:
       return
     self._launched[b] = True
@@ -141,9 +144,14 @@ class GradReducer:
     lo, hi, _ = self.buckets[b]
     chunk = self.flat.g[lo:hi]
     if self.cuda:
-      ev = torch.cuda.Event(enable_timing=self.profile)
-      ev.record(torch.cuda.current_stream(chunk.device))
-      self.comm_stream.wait_event(ev)
+      ev = None
+      if order_behind is not None:
+        order_behind(self.comm_stream)
+      if order_behind is None or self.profile:
+        ev = torch.cuda.Event(enable_timing=self.profile)
+        ev.record(torch.cuda.current_stream(chunk.device))
+      if order_behind is None:
+        self.comm_stream.wait_event(ev)
       with torch.cuda.stream(self.comm_stream):
         self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
         if self.profile:
