@@ -300,6 +300,41 @@ def log(msg):
   print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def timed_leg(loss, voxel, batch_size, steps, warmup, model="Res16UNet34C", overrides=()):
+  """One more workload on THIS GPU in the same process (N = 1 only): the full training iteration of `loss` at `voxel`,
+  `warmup` untimed + `steps` timed iterations bracketed by synchronisations.  Used for the extra.* legs of the JSON line
+  (BASELINE configs[2] = HardestContrastive, configs[4] shape = 1 cm voxels), so that the driver's own run witnesses
+  them next to the headline number."""
+  import torch
+  from pointcontrast_amd.lib import ddp_trainer
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  cfg = get_config(["net.model=%s" % model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1", "misc.num_gpus=1",
+                    "trainer.batch_size=%d" % batch_size] + list(overrides))
+  batch = get_batch(seed=0, batch_size=batch_size, voxel_size=voxel)
+  loader = FixedBatchLoader([batch], batch_size=batch_size)
+  torch.manual_seed(0)
+  np.random.seed(0)
+  cls = ddp_trainer.PointNCELossTrainer if loss == "nce" else ddp_trainer.HardestContrastiveLossTrainer
+  trainer = cls(cfg, loader)
+  it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
+  for _ in range(warmup):
+    res = trainer._train_iter(it, timers)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    res = trainer._train_iter(it, timers)
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  out = {"value": round(batch_size * steps / dt, 3), "unit": "scene-pairs/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+         "steps": steps, "warmup": warmup, "final_loss": round(float(res["loss"]), 5),
+         "voxels_per_forward_pair": [int(batch["sinput0_C"].shape[0]), int(batch["sinput1_C"].shape[0])]}
+  del trainer
+  torch.cuda.empty_cache()
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -312,6 +347,7 @@ def main():
   ap.add_argument("--engine", choices=["native", "autograd"], default="native")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
+  ap.add_argument("--no-extra", action="store_true", help="skip the extra.hardest / extra.voxel_1cm legs (N = 1 default run)")
   ap.add_argument("--layer-table", default=None, help="write the per-layer work table to this path")
   ap.add_argument("--set", action="append", default=[], metavar="a.b=c", help="extra config override (A/B experiments)")
   args = ap.parse_args()
@@ -332,9 +368,16 @@ def main():
   rank = int(os.environ.get("RANK", "0"))
   __graft_entry__.build()  # every rank: an exclusive file lock inside serialises them, all but the first find it built
   from pointcontrast_amd.lib import distributed as du
+  forced = any(a.replace(" ", "") in ("misc.force_reducer=True", "misc.force_reducer=1") for a in args.set)
   if world > 1:
     du.init_process_group()
     dist.barrier()
+  elif forced:
+    # --set misc.force_reducer=True on one GPU: the N > 1 code path (bucket callbacks -> RCCL all-reduce on the side
+    # stream -> one wait in front of SGD) in a 1-rank group -- what it costs the per-GPU step when nothing is exchanged
+    from pointcontrast_amd.lib.multiprocessing import free_port
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    du.init_process_group(0, 1)
   assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
   device = torch.device("cuda", torch.cuda.current_device())
 
@@ -345,7 +388,7 @@ def main():
   cfg = get_config(["net.model=%s" % args.model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1",
                     "misc.num_gpus=%d" % world, "trainer.batch_size=%d" % (args.batch * world),
                     "misc.engine=%s" % args.engine, "misc.host_profile=True",
-                    "misc.reducer_profile=%s" % (world > 1)] + list(args.set))
+                    "misc.reducer_profile=%s" % (world > 1 or forced)] + list(args.set))
   batch = get_batch(seed=rank, batch_size=args.batch, voxel_size=args.voxel)
   loader = FixedBatchLoader([batch], batch_size=args.batch)
   torch.manual_seed(0)
@@ -419,7 +462,7 @@ def main():
                                    "allreduce_mb_per_step": round(trainer.flat.numel * 4 / 2 ** 20, 1),
                                    "buckets": len(trainer.reducer.buckets),
                                    "overlap": trainer.reducer.overlap_report(skip_steps=args.warmup)}
-                                  if world > 1 else None)},
+                                  if (world > 1 or forced) else None)},
     }
     if args.layer_table:
       with open(args.layer_table, "w") as f:
@@ -430,39 +473,83 @@ def main():
     if not args.no_roofline:
       dom, kernels = kernel_rooflines(batch, device, joint=bool(cfg.misc.get("joint_pair", True)) and args.engine == "native")
       log("rooflines done")
+      # Which kernel is "the dominant one": launches per step of a shape (from the lowered program) x its stand-alone
+      # launch time = its estimated share of the step; the forward / backward-data convolution and the weight-gradient
+      # kernel of the level-1 96 -> 96 layers are both reported (`roofline` = the larger share, `roofline_other` = the
+      # other), each with its own fraction -- the weight-gradient kernel is the one further from its bound.
+      n96 = sum(1 for o in (trainer.engine._ops if trainer.engine is not None else [])
+                if o["type"] == 0 and o.get("cin") == 96 and o.get("cout") == 96 and o.get("kernel_size") == 3
+                and o.get("stride") == 1 and trainer.engine._tensors[o["out"]]["level"] == 0) or 3
+      wg = next(k for k in kernels if k["kernel"].startswith("wgrad") and "@level1" in k["kernel"])
+      share = {id(dom): 2 * n96 * dom["ms"], id(wg): n96 * wg["ms"]}  # fwd + bwd-data launches; one gradient launch per layer
+      first, second = (dom, wg) if share[id(dom)] >= share[id(wg)] else (wg, dom)
       # HBM-side bytes per launch of the same kernel / shape from the separate rocprofv3 --pmc passes
-      # (scripts/pmc_probe.py -> scripts/pmc_summary.py -> profiles/pmc_traffic.json); null if never collected
-      traffic = None
+      # (scripts/pmc_probe.py -> scripts/pmc_summary.py -> profiles/pmc_traffic.json); reported only when the file was
+      # collected on THIS build (kernel_sources_sha16 = sha256 over the kernel sources, headers and flags) and on this
+      # run's level-1 tensor (pair count); else null
+      from pointcontrast_amd.build import sources_digest
+      pmc, traffic_note = None, "profiles/pmc_traffic.json absent"
       try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-          per_launch = json.load(f)["bytes_per_launch"]
-        # the unit-balanced launch of this conv = main kernel + fix-up kernel (in pmc_probe.py only the 96->96 conv
-        # takes that launch, so the fix-up's per-launch average belongs to this shape)
-        # (the pmc file also says which level-1 tensor it was collected on: a count of pairs other than this run's
-        #  means a stale file, and the traffic is then not reported)
-        if dom["kernel"].startswith("spconv16x"):
-          names = ("spconv16x_kernel<3, true, true>",)
+          pmc = json.load(f)
+        if pmc.get("kernel_sources_sha16") != sources_digest()[:16]:
+          traffic_note = "PMC passes were collected on another build (%s), not on this one (%s)" % (
+              pmc.get("kernel_sources_sha16", "unstamped"), sources_digest()[:16])
+          pmc = None
+        elif pmc.get("algorithmic", {}).get("96->96", {}).get("pairs") != dom["pairs"]:
+          traffic_note = "PMC passes were collected on another level-1 tensor"
+          pmc = None
         else:
-          names = ("spconv16p_kernel<3, false, true>", "spconv16_kernel<3, false, true>",
-                   "spconv_mfma_kernel<3, 4, false, false, true, 32, 256>")
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-          same_shape = json.load(f).get("algorithmic", {}).get("96->96", {}).get("pairs") == dom["pairs"]
-        for name in names if same_shape else ():
-          if name in per_launch:
-            traffic = per_launch[name] + per_launch.get("sk_fixup_kernel", 0.0)
-            break
-      except (OSError, ValueError, KeyError):
+          traffic_note = "PMC passes of this build: profiles/%s" % pmc.get("source", "?")
+      except (OSError, ValueError):
         pass
-      out["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                         "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (PMC, calibrated)",
-                         "kernel": dom["kernel"], "ms": dom["ms"],
-                         **{k: dom[k] for k in ("arithmetic", "peak_fp32_mfma", "frac_of_fp32_mfma_peak") if k in dom}}
+
+      def traffic_of(ent):
+        if pmc is None:
+          return None
+        per = pmc["bytes_per_launch"]
+        if ent["kernel"].startswith("wgrad"):
+          names, extra = ("wgrad_x3t_kernel<3, 3, 4>", "wgrad_x3t_kernel<3, 3, 8>", "wgrad_mfma_kernel<3, 3, true, true>"), "wgrad_slab_sum_kernel"
+        elif ent["kernel"].startswith("spconv16x"):
+          names, extra = ("spconv16x_kernel<3, true, true>",), "sk_fixup_kernel"
+        else:
+          names, extra = ("spconv16p_kernel<3, false, true>",), "sk_fixup_kernel"
+        for name in names:
+          if name in per:
+            return per[name] + per.get(extra, 0.0)
+        return None
+
+      def roofline_of(ent):
+        return {"bound": ent["bound"], "achieved": ent["achieved"], "peak": ent["peak"], "unit": ent["unit"],
+                "frac": ent["frac"], "traffic": traffic_of(ent), "traffic_unit": "bytes/launch (PMC, calibrated)",
+                "traffic_note": traffic_note, "kernel": ent["kernel"], "ms": ent["ms"],
+                "launches_per_step": (2 if ent is dom else 1) * n96, "est_step_share_ms": round(share[id(ent)], 3),
+                **{k: ent[k] for k in ("arithmetic", "peak_fp32_mfma", "frac_of_fp32_mfma_peak") if k in ent}}
+
+      out["roofline"] = roofline_of(first)
+      out["roofline_other"] = roofline_of(second)
       out["kernels"] = kernels
+    if world == 1 and not args.no_extra and workload_label(args) == "BASELINE configs[1]":
+      # the other two single-GPU-measurable BASELINE configurations, short legs in the same process (same build, same box)
+      del trainer, it, loader
+      torch.cuda.empty_cache()
+      out["extra"] = {}
+      for key, kw in (("hardest", dict(loss="hardest", voxel=0.025, steps=10, warmup=3)),
+                      ("voxel_1cm", dict(loss="nce", voxel=0.01, steps=6, warmup=3))):
+        log("extra leg: %s" % key)
+        try:
+          leg = timed_leg(batch_size=args.batch, model=args.model, overrides=list(args.set), **kw)
+          leg["workload"] = ("BASELINE configs[2]: HardestContrastive, 2.5 cm" if key == "hardest"
+                             else "BASELINE configs[4] shape: PointInfoNCE, 1 cm voxels, on 1 GPU")
+          out["extra"][key] = leg
+        except Exception as e:  # the headline number must not be lost to a failing extra leg
+          out["extra"][key] = {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = run_cpu_baseline_bounded()
     print(json.dumps(out), flush=True)
   if world > 1:
     dist.barrier()
+  if world > 1 or forced:
     du.destroy_process_group()
 
 

@@ -35,6 +35,17 @@ def _digest(paths):
   return h.hexdigest()
 
 
+def _headers():
+  return [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "spconv_args.h"),
+          os.path.join(CSRC, "x3_split.h"), os.path.join(HERE, "..", "include", "pcmi.h")]
+
+
+def sources_digest():
+  """sha256 over every kernel source, header and the compiler flags: names the build a measurement was taken on
+  (profiles/pmc_traffic.json carries it; bench.py reports PMC traffic only for the build it runs)."""
+  return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers())
+
+
 def build_lib(force=False, verbose=False):
   """Compiles what changed and links libpcmi.so.  Safe to call from several processes at once (the ranks of a
   multi-GPU run all call it): an exclusive file lock serialises them, the first one builds, the others find the
@@ -51,7 +62,7 @@ def build_lib(force=False, verbose=False):
 
 
 def _build_locked(force, verbose):
-  headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "spconv_args.h"), os.path.join(CSRC, "x3_split.h"), os.path.join(HERE, "..", "include", "pcmi.h")]
+  headers = _headers()
   hipcc = _hipcc()
 
   def compile_one(src):

@@ -146,6 +146,17 @@ static int check_insert_status(pcmi_coords* h) {
   return PCMI_OK;
 }
 
+// a duplicate / out-of-range row: the handle holds nothing afterwards (levels, maps and both arenas), whichever call
+// found out -- the synchronous insert, the level chain or the end of pcmi_coords_plan_unet
+static void discard_after_bad_insert(pcmi_coords_t* h) {
+  h->levels.clear();
+  h->maps.clear();
+  h->pending.clear();
+  h->plan_recorded = false;
+  h->persistent.reset();
+  h->scratch.reset();
+}
+
 namespace pcmi {
 
 // ---------------------------------------------------------------------------------------------
@@ -595,7 +606,7 @@ static int coords_insert_impl(pcmi_coords_t* h, const int32_t* bxyz, int64_t n, 
   if (deferred) return PCMI_OK;
   PCMI_HIP_CHECK(hipStreamSynchronize(st));
   rc = check_insert_status(h);
-  if (rc) h->levels.clear();
+  if (rc) discard_after_bad_insert(h);
   return rc;
 }
 
@@ -611,7 +622,9 @@ int pcmi_coords_check(pcmi_coords_t* h, pcmi_stream_t stream) {
   PCMI_REQUIRE(h, PCMI_ERR_INVALID, "null handle");
   if (!h->insert_unchecked) return PCMI_OK;
   PCMI_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
-  return check_insert_status(h);
+  const int rc = check_insert_status(h);
+  if (rc) discard_after_bad_insert(h);
+  return rc;
 }
 
 int pcmi_coords_size(pcmi_coords_t* h, int key, int64_t* n, int* tensor_stride) {
@@ -954,8 +967,8 @@ static int build_level_chain(pcmi_coords_t* h, int n_down, hipStream_t st) {
   PCMI_HIP_CHECK(hipMemcpyAsync(h->h_pinned + kLevelSlot0, h->d_counts, sizeof(int64_t) * 2 * kMaxLevels, hipMemcpyDeviceToHost, st));
   PCMI_HIP_CHECK(hipStreamSynchronize(st));
   int rc = check_insert_status(h);
-  if (rc) {
-    h->levels.resize(1);
+  if (rc) {  // as the synchronous insert: the handle holds nothing (a table with a bad hash must not stay usable)
+    discard_after_bad_insert(h);
     return rc;
   }
   for (int l = 0; l < n_down; ++l) {
@@ -1003,6 +1016,16 @@ int pcmi_coords_plan_unet(pcmi_coords_t* h, int n_down, int first_region, int bl
     key = ck;
   }
   h->defer_maps = false;
+  // a deferred insert reports its duplicate / range status through this call (pcmi.h): when no level chain was built
+  // (n_down == 0, or levels that already existed) nothing above has synchronised and looked at it yet
+  if (h->insert_unchecked) {
+    PCMI_HIP_CHECK(hipStreamSynchronize(st));
+    rc = check_insert_status(h);
+    if (rc) {
+      discard_after_bad_insert(h);
+      return rc;
+    }
+  }
   PCMI_HIP_CHECK(hipEventRecord(h->ev_plan, st));
   h->plan_recorded = true;
   return PCMI_OK;

@@ -98,6 +98,10 @@ struct PassState {
   std::vector<size_t> grad_off;
   DevBuf small;  // dgamma / dbeta scratch
   ~PassState() {
+    for (int i = 0; i < 2; ++i) {
+      if (x3_jobs_host[i]) (void)hipHostFree(x3_jobs_host[i]);
+      if (x3_jobs_copied[i]) (void)hipEventDestroy(x3_jobs_copied[i]);
+    }
     if (upd_host) (void)hipHostFree(upd_host);
     if (upd_dev) (void)hipFree(upd_dev);
     if (upd_copied) (void)hipEventDestroy(upd_copied);
@@ -114,6 +118,24 @@ struct PassState {
   int64_t out_ld = 0;
   pcmi_coords_t* coords = nullptr;
   bool valid = false;
+  // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
+  // top of this pass's forward (x3_prepack) instead of one pack launch in front of every convolution.  Per PASS, not
+  // per network: two passes of an iteration may fall into different size classes (different slice widths = different
+  // pack layouts) and may be in flight on two streams at once; each reads its own packs and its own job table.
+  DevBuf x3_packs, x3_jobs_dev;
+  std::vector<X3Prepacked> x3_table;
+  std::vector<int> x3_nts;  // slice width per (conv op, orientation) the table was built for
+  const float* x3_params = nullptr;
+  bool x3_current = false;  // the last forward of this pass packed (the packs are those of its weights)
+  int x3_n_jobs = 0;
+  int64_t x3_items = 0;
+  // the job table goes up through pinned host memory with an asynchronous copy ON the pass's stream: ordered behind
+  // the pack kernel of the previous table still queued there, and the enqueueing thread does not wait for the queue
+  // to drain (a pageable hipMemcpy would).  Two host buffers: a rebuild waits only for the copy before the last.
+  X3PackJob* x3_jobs_host[2] = {nullptr, nullptr};
+  size_t x3_jobs_host_cap[2] = {0, 0};
+  hipEvent_t x3_jobs_copied[2] = {nullptr, nullptr};
+  int x3_jobs_slot = 0;
 };
 
 }  // namespace pcmi
@@ -133,15 +155,6 @@ struct pcmi_net {
   hipEvent_t ev_bkt_main = nullptr, ev_bkt_side = nullptr;
   bool bkt_valid = false, bkt_side = false;
   pcmi::DevBuf ws_side[1];
-  // split-precision convolutions: the weights of every eligible layer, both orientations, packed by ONE launch at the
-  // top of a forward pass (x3_prepack) instead of one pack launch in front of every convolution
-  pcmi::DevBuf x3_packs, x3_jobs_dev;
-  std::vector<pcmi::X3Prepacked> x3_table;
-  std::vector<int> x3_nts;  // slice width per (conv op, orientation) the table was built for
-  const float* x3_params = nullptr;
-  bool x3_current = false;  // the last forward pass packed (the packs are those of its weights)
-  int x3_n_jobs = 0;
-  int64_t x3_items = 0;
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
   ~pcmi_net() {
     (void)hipDeviceSynchronize();
@@ -201,18 +214,18 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
 
 // Packs the weights of every layer the split-precision kernel can take (3^3 / 2^3 convolutions with >= 64 channels on
 // both sides), forward and backward-data orientation, in one launch on `st`, and makes the table current for this
-// thread's convolution calls.  The job table is built once per parameter buffer.  PCMI_X3_PREPACK=0: every convolution
-// packs its own weights in front of its launch (as the C-ABI entry points do).
-static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st, const std::vector<int64_t>& rows) {
+// thread's convolution calls.  The job table is rebuilt when the parameter buffer changes or a level crosses a size
+// class (its slice width changes).  PCMI_X3_PREPACK=0: every convolution packs its own weights in front of its launch
+// (as the C-ABI entry points do).
+static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream_t st) {
   const char* pe = getenv("PCMI_X3_PREPACK");  // read per pass: the parity test runs both forms in one process
   const bool enabled = !(pe && pe[0] == '0');
-  n.x3_current = false;
+  ps.x3_current = false;
   if (!enabled || !pcmi_spconv_split_precision()) {
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
   }
-  // slice width of every (layer, orientation) for THIS pass's level sizes (a level that crosses a size class between two
-  // batches changes it): the job table is rebuilt when the parameter buffer or any width changes
+  const std::vector<int64_t>& rows = ps.rows;
   std::vector<int> nts;
   for (const auto& op : n.ops) {
     if (op.type != PCMI_OP_CONV || op.kernel_size <= 1) continue;
@@ -222,11 +235,10 @@ static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st, const st
       nts.push_back(x3_plan_nt(rows[n.tensors[tr ? op.in : op.out].level], C, N, K));
     }
   }
-  if (n.x3_params != params || nts != n.x3_nts) {
-    n.x3_nts = nts;
+  if (ps.x3_params != params || nts != ps.x3_nts) {
     size_t slot = 0;
     std::vector<X3PackJob> jobs;
-    n.x3_table.clear();
+    std::vector<X3Prepacked> table;
     size_t bytes = 0;
     int64_t items = 0;
     for (const auto& op : n.ops) {
@@ -248,46 +260,64 @@ static int x3_prepack(pcmi_net& n, const float* params, hipStream_t st, const st
         j.out = (void*)bytes;  // offset for now
         j.first_item = items;
         jobs.push_back(j);
-        n.x3_table.push_back({j.w, tr, NT, (const void*)bytes});
+        table.push_back({j.w, tr, NT, (const void*)bytes});
         bytes += x3_pack_bytes(K, C, N);
         items += (int64_t)K * (C / 32) * N * 4;
       }
     }
-    n.x3_n_jobs = (int)jobs.size();
-    n.x3_items = items;
     if (!jobs.empty()) {
-      int rc = n.x3_packs.reserve(bytes, st);
+      // (a growing buffer drains the device first -- DevBuf::reserve -- so nothing in flight reads the old block)
+      int rc = ps.x3_packs.reserve(bytes, st);
       if (rc) return rc;
-      rc = n.x3_jobs_dev.reserve(jobs.size() * sizeof(X3PackJob), st);
+      rc = ps.x3_jobs_dev.reserve(jobs.size() * sizeof(X3PackJob), st);
       if (rc) return rc;
       for (size_t i = 0; i < jobs.size(); ++i) {
-        jobs[i].out = n.x3_packs.p + (size_t)jobs[i].out;
-        n.x3_table[i].pack = n.x3_packs.p + (size_t)n.x3_table[i].pack;
+        jobs[i].out = ps.x3_packs.p + (size_t)jobs[i].out;
+        table[i].pack = ps.x3_packs.p + (size_t)table[i].pack;
       }
-      // (pageable source: the copy has left the host buffer when the call returns)
-      PCMI_HIP_CHECK(hipMemcpy(n.x3_jobs_dev.p, jobs.data(), jobs.size() * sizeof(X3PackJob), hipMemcpyHostToDevice));
+      const int hs = ps.x3_jobs_slot;
+      ps.x3_jobs_slot ^= 1;
+      const size_t need = jobs.size() * sizeof(X3PackJob);
+      if (!ps.x3_jobs_copied[hs]) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_jobs_copied[hs], hipEventDisableTiming));
+      PCMI_HIP_CHECK(hipEventSynchronize(ps.x3_jobs_copied[hs]));  // the copy that last read this host buffer (two tables ago)
+      if (need > ps.x3_jobs_host_cap[hs]) {
+        if (ps.x3_jobs_host[hs]) PCMI_HIP_CHECK(hipHostFree(ps.x3_jobs_host[hs]));
+        ps.x3_jobs_host[hs] = nullptr;
+        ps.x3_jobs_host_cap[hs] = 0;
+        PCMI_HIP_CHECK(hipHostMalloc((void**)&ps.x3_jobs_host[hs], 2 * need, hipHostMallocDefault));
+        ps.x3_jobs_host_cap[hs] = 2 * need;
+      }
+      memcpy(ps.x3_jobs_host[hs], jobs.data(), need);
+      // in stream order: behind the previous table's pack kernel (and every convolution that read its packs) on `st`
+      PCMI_HIP_CHECK(hipMemcpyAsync(ps.x3_jobs_dev.p, ps.x3_jobs_host[hs], need, hipMemcpyHostToDevice, st));
+      PCMI_HIP_CHECK(hipEventRecord(ps.x3_jobs_copied[hs], st));
     }
-    n.x3_params = params;
+    ps.x3_table.swap(table);
+    ps.x3_nts.swap(nts);
+    ps.x3_n_jobs = (int)jobs.size();
+    ps.x3_items = items;
+    ps.x3_params = params;
   }
-  if (n.x3_n_jobs == 0) {
+  if (ps.x3_n_jobs == 0) {
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
   }
-  const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(n.x3_jobs_dev.p), n.x3_n_jobs, n.x3_items, st);
+  const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(ps.x3_jobs_dev.p), ps.x3_n_jobs, ps.x3_items, st);
   if (rc) return rc;
-  n.x3_current = true;
-  x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
+  ps.x3_current = true;
+  x3_set_prepacked(ps.x3_table.data(), (int)ps.x3_table.size());
   return PCMI_OK;
 }
 
 // Clears the calling thread's table of packed weights on scope exit.  The backward form first makes the packs of the
-// last forward pass current again -- if that pass packed at all (x3_current): they are those of `params` as long as the
-// weights have not been touched since (a backward pass differentiates the forward pass that produced them, so they
-// have not).
+// pass's last forward current again -- if that forward packed at all (x3_current): they are those of `params` as long
+// as the weights have not been touched since (a backward pass differentiates the forward pass that produced them, so
+// they have not).  A layer whose level changed its size class in between simply does not find its (weights,
+// orientation, width) entry and packs for itself.
 struct X3TableScope {
   X3TableScope() = default;
-  X3TableScope(const pcmi_net& n, const float* params) {
-    if (n.x3_current && n.x3_n_jobs > 0 && n.x3_params == params) x3_set_prepacked(n.x3_table.data(), (int)n.x3_table.size());
+  X3TableScope(const PassState& ps, const float* params) {
+    if (ps.x3_current && ps.x3_n_jobs > 0 && ps.x3_params == params) x3_set_prepacked(ps.x3_table.data(), (int)ps.x3_table.size());
   }
   X3TableScope(const X3TableScope&) = delete;
   X3TableScope& operator=(const X3TableScope&) = delete;
@@ -472,7 +502,7 @@ struct BackwardRun {
 
 static int run_backward(pcmi_net& n, const BackwardJob& job, const float* params, float* grads,
                         const int64_t* bucket_lo_host, int n_buckets, pcmi_ready_fn ready, void* ready_ctx) {
-  const X3TableScope x3_scope(n, params);
+  const X3TableScope x3_scope(n.passes[job.pass], params);
   BackwardRun r(n, job, params, grads, bucket_lo_host, n_buckets, ready, ready_ctx);
   int rc = r.begin();
   for (int i = (int)n.ops.size() - 1; i >= 0 && !rc; --i) rc = r.step(i);
@@ -585,7 +615,7 @@ int pcmi_net_export_tensor(pcmi_net_t* net, int pass, int tensor, int64_t* rows,
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
   size_t b = net->ws_side[0].cap;
-  for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap;
+  for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap + p.x3_packs.cap + p.x3_jobs_dev.cap;
   *bytes = b;
   return PCMI_OK;
 }
@@ -698,7 +728,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.coords = coords;
   // (the pack on a side stream, joined in front of the first convolution that needs it, was measured: 237.7 against
   //  238.3 pairs/s in line -- profiles/r03c_bench_ab.txt -- and is gone)
-  rc = x3_prepack(n, params, st, ps.rows);
+  rc = x3_prepack(n, ps, params, st);
   const X3TableScope x3_scope;  // the table is this thread's only until the pass has been enqueued
   if (rc) return rc;
   g_prof_fwd.lap(2);

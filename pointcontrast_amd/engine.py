@@ -177,6 +177,7 @@ class NativeEngine:
     self.in_channels, self.out_channels, self.n_down = in_channels, prog["out_channels"], prog["n_down"]
     self._bn_modules = prog["bn_modules"]
     self.n_ops, self.n_tensors = len(prog["ops"]), len(prog["tensors"])
+    self._tensors = prog["tensors"]  # {level, channels, parent, col_off} per tensor id
     self._ops = prog["ops"]  # the lowered program (dicts): which op writes which tensor (activation / relu_masks)
     self._h = create_net(prog, n_passes)
     self._held = [None] * n_passes

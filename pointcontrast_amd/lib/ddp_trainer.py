@@ -134,7 +134,7 @@ class ContrastiveLossTrainer:
       st = self._staging = {}
     buf, ev = st.get(slot, (None, None))
     if buf is None or buf.numel() < n:
-      buf = torch.empty(max(n, 8192), dtype=torch.int64).pin_memory()
+      buf = torch.empty(int(n * 1.25) + 8192, dtype=torch.int64).pin_memory()
       ev = None
     if ev is not None:
       ev.synchronize()  # the previous iteration's copy out of this buffer (long finished)
@@ -468,7 +468,9 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     n = t_cpu.numel()
     buf, ev = st.get(slot, (None, None))
     if buf is None or buf.numel() < n or buf.dtype != t_cpu.dtype:
-      buf, ev = torch.empty(max(n, 8192), dtype=t_cpu.dtype).pin_memory(), None
+      # 25 % head-room (as the device workspace below): the buffer converges after a few batches instead of being
+      # re-pinned -- milliseconds per hipHostMalloc, on the preparation path -- at every new maximum
+      buf, ev = torch.empty(int(n * 1.25) + 8192, dtype=t_cpu.dtype).pin_memory(), None
     if ev is not None:
       ev.synchronize()
     buf[:n].copy_(t_cpu.reshape(-1))

@@ -32,13 +32,29 @@ class FlatSGD(torch.optim.Optimizer):
                 dampening=g.get("dampening", 0.0), first_step=self._fresh)
     self._fresh = False
 
+  def state_dict(self):
+    """torch's layout plus `pcmi_steps_taken` in the (single) param group: whether the optimiser has stepped.  torch
+    encodes that as "the momentum buffers exist"; here they always do, so a checkpoint written before the first step
+    would otherwise resume with dampening already applied to the first gradient."""
+    sd = super().state_dict()
+    sd["param_groups"][0]["pcmi_steps_taken"] = 0 if self._fresh else 1
+    return sd
+
   def load_state_dict(self, state_dict):
     super().load_state_dict(state_dict)
+    taken = self.param_groups[0].pop("pcmi_steps_taken", None)
+    any_buf, any_nonzero = False, False
     with torch.no_grad():
       for i, p in enumerate(self.flat.params):
         buf = self.state[p].get("momentum_buffer")
         view = self.flat.view(self.flat.v, i)
-        if buf is not None and buf.data_ptr() != view.data_ptr():
-          view.copy_(buf.to(view.device))
+        if buf is not None:
+          any_buf = True
+          if buf.data_ptr() != view.data_ptr():
+            view.copy_(buf.to(view.device))
         self.state[p]["momentum_buffer"] = view
-        self._fresh = self._fresh and buf is None  # loaded buffers: the run being resumed has stepped before
+      if taken is None and any_buf:  # a checkpoint of torch.optim.SGD, or of a build without the flag: derive it
+        any_nonzero = bool(torch.count_nonzero(self.flat.v).item())
+    # fresh = no step has been taken by the run being resumed: the flag when the checkpoint carries it, else "no
+    # momentum buffer holds anything" (torch writes none before the first step; this class wrote zero-filled ones)
+    self._fresh = (taken == 0) if taken is not None else not any_nonzero

@@ -75,6 +75,9 @@ try:
 except (OSError, KeyError, IndexError) as e:
   md += ["", "(no LDS / stall pass: %s)" % e]
 open(os.path.join(root, "profiles", "%s_pmc_summary.md" % tag), "w").write("\n".join(md) + "\n")
-json.dump({"source": "%s_pmc_summary.md" % tag, "bytes_per_launch": traffic, "algorithmic": algo},
+sys.path.insert(0, root)
+from pointcontrast_amd.build import sources_digest  # noqa: E402  (the build these counters were collected on)
+json.dump({"source": "%s_pmc_summary.md" % tag, "kernel_sources_sha16": sources_digest()[:16], "bytes_per_launch": traffic,
+           "algorithmic": algo},
           open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(md))

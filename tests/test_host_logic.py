@@ -417,3 +417,48 @@ def test_pairs_scan_host_counts_runs_and_detects_unsorted_input(built_lib):
     if n > 10:
       pp[n // 2, 0] = -1
       assert PF.pairs_scan_host(pp)[1] is False
+
+
+def test_flat_sgd_first_step_flag_survives_a_checkpoint(built_lib):
+  """torch's SGD copies the gradient into the momentum buffer on the first step (no dampening); FlatSGD's buffers exist
+  from the start, so "has stepped" travels in the state dict -- a checkpoint written before the first step must not
+  resume with dampening applied (downstream fine-tuning: dampening 0.1, downstream/semseg/lib/solvers.py:52-60)."""
+  import torch
+  from pointcontrast_amd.lib import distributed as du
+  from pointcontrast_amd.lib.solver import FlatSGD
+
+  def make():
+    torch.manual_seed(0)
+    m = torch.nn.Linear(4, 3)
+    flat = du.FlatParameters(m.parameters())
+    return m, flat, FlatSGD(flat, lr=0.1, momentum=0.9, dampening=0.1)
+
+  _, _, fresh = make()
+  sd = fresh.state_dict()
+  assert sd["param_groups"][0]["pcmi_steps_taken"] == 0
+  _, _, o = make()
+  o._fresh = False
+  o.load_state_dict(sd)
+  assert o._fresh and "pcmi_steps_taken" not in o.param_groups[0]
+  # after a step
+  _, flat, stepped = make()
+  stepped._fresh = False
+  flat.v.fill_(0.5)
+  sd = stepped.state_dict()
+  assert sd["param_groups"][0]["pcmi_steps_taken"] == 1
+  _, flat2, o = make()
+  o.load_state_dict(sd)
+  assert not o._fresh and all(torch.equal(flat2.view(flat2.v, i), flat.view(flat.v, i)) for i in range(2))
+  # a checkpoint without the flag (torch.optim.SGD's, or an older build's): derived from the buffers
+  sd_old = stepped.state_dict()
+  del sd_old["param_groups"][0]["pcmi_steps_taken"]
+  _, _, o = make()
+  o.load_state_dict(sd_old)
+  assert not o._fresh
+  flat.v.zero_()
+  sd_zero = stepped.state_dict()
+  del sd_zero["param_groups"][0]["pcmi_steps_taken"]
+  _, _, o = make()
+  o._fresh = False
+  o.load_state_dict(sd_zero)
+  assert o._fresh
