@@ -46,6 +46,18 @@ def sources_digest():
   return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
+def build_variant(name, extra_flags, force=False, verbose=False):
+  """An A/B build of the SAME sources with extra compiler flags: objects in csrc/_build_<name>/, library
+  pointcontrast_amd/libpcmi_<name>.so (select it with PCMI_LIB=<path>; scripts/gpu A/B runs).  Not the product build."""
+  global BUILD, LIB, FLAGS
+  saved = (BUILD, LIB, FLAGS)
+  try:
+    BUILD, LIB, FLAGS = os.path.join(CSRC, "_build_" + name), os.path.join(HERE, "libpcmi_%s.so" % name), FLAGS + list(extra_flags)
+    return build_lib(force=force, verbose=verbose)
+  finally:
+    BUILD, LIB, FLAGS = saved
+
+
 def build_lib(force=False, verbose=False):
   """Compiles what changed and links libpcmi.so.  Safe to call from several processes at once (the ranks of a
   multi-GPU run all call it): an exclusive file lock serialises them, the first one builds, the others find the

@@ -149,6 +149,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
 #define PCMI_WX3_MFMA(AT, BT)                                                                                              \
   acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[mt]), __builtin_bit_cast(bf16x8, BT), \
                                                            acc[s][mt][nt], 0, 0, 0)
+#if defined(PCMI_X3_BACK_TO_BACK)
+          // A/B build: the six products of ONE tile back to back on its accumulator, tile after tile
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
+            PCMI_WX3_MFMA(al, bh);
+            PCMI_WX3_MFMA(ah, bl);
+            PCMI_WX3_MFMA(am, bm);
+            PCMI_WX3_MFMA(am, bh);
+            PCMI_WX3_MFMA(ah, bm);
+            PCMI_WX3_MFMA(ah, bh);
+          }
+#else
           // six products per tile, the small ones first; the MTW tiles of a term alternate (independent accumulators)
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(al, bh);
@@ -162,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
           for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bm);
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bh);
+#endif
 #undef PCMI_WX3_MFMA
         }
       }

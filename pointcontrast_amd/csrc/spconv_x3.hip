@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     stage_b(true, 0);
     va0 = stage_a(a0, true);
     store_b(0);
+#if defined(PCMI_X3_EARLY_B)
+    stage_meta();
+#endif
     __syncthreads();  // (DMA: the barrier's fence waits for the block to have landed)
     auto do_step = [&](int step, v4f (&cur)[2][2], int va_cur, v4f (&nxt)[2][2], int& va_nxt) {
       const bool more = step + 1 < nsteps;
@@ -370,6 +373,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
   PCMI_X3_MFMA(G, am, bh);  \
   PCMI_X3_MFMA(G, ah, bm);  \
   PCMI_X3_MFMA(G, ah, bh)
+#if defined(PCMI_X3_BACK_TO_BACK)
+        // A/B build: the six products of a row group back to back on ONE accumulator (the matrix pipe forwards an
+        // accumulator to the next MFMA only when nothing is issued in between), then the other group's
+        if (g0 && g1) {
+          PCMI_X3_SIX(0);
+          PCMI_X3_SIX(1);
+        } else
+#endif
         if (g0 && g1) {
           PCMI_X3_MFMA(0, al, bh);
           PCMI_X3_MFMA(1, al, bh);
@@ -391,9 +402,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
 #undef PCMI_X3_SIX
 #undef PCMI_X3_MFMA
         // the next step's operands, requested in the shadow of this step's MFMAs
+#if defined(PCMI_X3_EARLY_B)
+        // A/B build (libpcmi_earlyb.so): the weight block of the next step is requested behind the FIRST column tile
+        // (its look-up was staged at the end of the step before), the gathers behind the second
+        if (ct == 0) stage_b(more, (step + 1) & 1);
+        if (ct == 1) va_nxt = stage_a(nxt, more);
+        if (ct == CTN - 1) stage_meta();
+#else
         if (ct == 0) stage_meta();
         if (ct == 1) stage_b(more, (step + 1) & 1);
         if (ct == 2) va_nxt = stage_a(nxt, more);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (more) store_b((step + 1) & 1);
