@@ -88,12 +88,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
       const uint32_t col = (uint32_t)(ch0 + 4 * q_s) * 4u;
 #pragma unroll
       for (int e = 0; e < 8; ++e)  // an absent row has an offset >= 2^31: out of range, the load returns zeros
+#if defined(PCMI_X3_DIAG_NO_GATHER)  // timing diagnostic (wrong results): every row out of range = no memory traffic
+        v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, kAbsent + (offs[8 * rg_s + e] & 0u) + col, 0, 0));
+#else
         v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offs[8 * rg_s + e] + col, 0, 0));
+#endif
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         const v4f x0 = {v[0][e4], v[1][e4], v[2][e4], v[3][e4]}, x1 = {v[4][e4], v[5][e4], v[6][e4], v[7][e4]};
         u32x4 h, m, l;
+#if defined(PCMI_X3_DIAG_NO_SPLIT)  // timing diagnostic (wrong results)
+        h = __builtin_bit_cast(u32x4, x0); m = __builtin_bit_cast(u32x4, x1); l = h;
+#else
         split3(x0, x1, h, m, l);
+#endif
         const int cell = rg_s * width + ((4 * q_s + e4) ^ rg_s);
         dst[cell] = h;
         dst[RG * width + cell] = m;
@@ -146,11 +154,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
         for (int nt = 0; nt < NTW; ++nt) {
           const int cell = rgq * NB + ((16 * (wn * NTW + nt) + i) ^ rgq);
           const u32x4 bh = s_g[cell], bm = s_g[RG * NB + cell], bl = s_g[2 * RG * NB + cell];
+#if defined(PCMI_X3_DIAG_NO_MFMA)  // timing diagnostic (wrong results)
+#define PCMI_WX3_MFMA(AT, BT) asm volatile("" ::"v"(AT[mt]), "v"(BT))
+#else
 #define PCMI_WX3_MFMA(AT, BT)                                                                                              \
   acc[s][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[mt]), __builtin_bit_cast(bf16x8, BT), \
                                                            acc[s][mt][nt], 0, 0, 0)
-#if defined(PCMI_X3_BACK_TO_BACK)
-          // A/B build: the six products of ONE tile back to back on its accumulator, tile after tile
+#endif
+          // six products per tile, the small ones first, back to back on the tile's accumulator, tile after tile (round 3
+          // alternated the MTW tiles of a term: same sums, same order per accumulator, a little slower -- profiles/r04e_*)
 #pragma unroll
           for (int mt = 0; mt < MTW; ++mt) {
             PCMI_WX3_MFMA(al, bh);
@@ -160,21 +172,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
             PCMI_WX3_MFMA(ah, bm);
             PCMI_WX3_MFMA(ah, bh);
           }
-#else
-          // six products per tile, the small ones first; the MTW tiles of a term alternate (independent accumulators)
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(al, bh);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bl);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(am, bm);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(am, bh);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bm);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) PCMI_WX3_MFMA(ah, bh);
-#endif
 #undef PCMI_WX3_MFMA
         }
       }

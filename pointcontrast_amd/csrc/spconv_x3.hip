@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256) void x3_pack_many_kernel(const X3PackJob* __re
   blk[2 * jb.NS * 4 + piece] = l;
 }
 
+// -DPCMI_X3_DIAG_NO_{GATHER,DMA,SPLIT,BFRAG,MFMA,BARRIER}: timing diagnostics -- one component compiled out, wrong results, for
+// stand-alone timing only (pointcontrast_amd.build.build_variant + PCMI_LIB; profiles/r04e_kernel_component_removal.txt
+// is what they showed: no single component bounds the kernel, and it is NOT memory latency -- requesting the gathers, or
+// gathers and weight blocks, two steps ahead changed nothing: profiles/r04b_*, r04f_*).
 template <int NT, bool SK, bool DMA>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArgs a) {
   constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
@@ -299,7 +303,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     l_voff[1] = *reinterpret_cast<const uint32_t*>(row + 64);
     const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wofs + (uint32_t)lc * chunk_bytes));
     if constexpr (DMA) {
+#if !defined(PCMI_X3_DIAG_NO_DMA)  // timing diagnostic (wrong results): the weight blocks are never staged
       if (live) dma_b(nbuf, soff);
+#endif
     } else {
 #pragma unroll
       for (int q = 0; q < BR; ++q)
@@ -310,7 +316,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     const uint32_t v0 = live ? l_voff[0] : kAbsent, v1 = live ? l_voff[1] : kAbsent;
     const int va = (__any(v0 != kAbsent) ? 1 : 0) | (__any(v1 != kAbsent) ? 2 : 0);
     const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(lc * (kKC * 4));
+#if defined(PCMI_X3_DIAG_NO_GATHER)  // timing diagnostic (wrong results): every gather out of range = no memory traffic
+    const uint32_t o0 = kAbsent, o1 = kAbsent;
+#else
     const uint32_t o0 = v0 + 16 * kk, o1 = v1 + 16 * kk;  // absent stays out of range
+#endif
     dst[0][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0, soff, 0));
     dst[1][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o1, soff, 0));
     dst[0][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(xr, o0 + 64, soff, 0));
@@ -323,9 +333,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     stage_b(true, 0);
     va0 = stage_a(a0, true);
     store_b(0);
-#if defined(PCMI_X3_EARLY_B)
-    stage_meta();
-#endif
     __syncthreads();  // (DMA: the barrier's fence waits for the block to have landed)
     auto do_step = [&](int step, v4f (&cur)[2][2], int va_cur, v4f (&nxt)[2][2], int& va_nxt) {
       const bool more = step + 1 < nsteps;
@@ -342,30 +349,47 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
       const bool g0 = (va_cur & 1) != 0, g1 = (va_cur & 2) != 0;
       // the gathered rows of this step as three bf16 terms
       u32x4 ah[2], am[2], al[2];
+#if defined(PCMI_X3_DIAG_NO_SPLIT)  // timing diagnostic (wrong results): no operand split, the raw bits stand in for the terms
+      ah[0] = __builtin_bit_cast(u32x4, cur[0][0]); am[0] = __builtin_bit_cast(u32x4, cur[0][1]); al[0] = ah[0];
+      ah[1] = __builtin_bit_cast(u32x4, cur[1][0]); am[1] = __builtin_bit_cast(u32x4, cur[1][1]); al[1] = ah[1];
+#else
       if (g0) split3(cur[0][0], cur[0][1], ah[0], am[0], al[0]);
       if (g1) split3(cur[1][0], cur[1][1], ah[1], am[1], al[1]);
+#endif
       // B fragments of column tile ct: piece (term, n = 16 ct + i, kk); a two-tile register ring, read one tile ahead
       const u32x4* sb = &s_b[step & 1][kk * 16 + i];  // x3_piece(16 ct + i, kk) = 64 ct + this
       u32x4 bh[2], bm[2], bl[2];
+#if defined(PCMI_X3_DIAG_NO_BFRAG)  // timing diagnostic (wrong results): no fragment reads from LDS, a register stands in
+      bh[0] = bm[0] = bl[0] = bh[1] = bm[1] = bl[1] = ah[0];
+      (void)sb;
+#else
       if (va_cur) {
         bh[0] = sb[0 * NS * 4];
         bm[0] = sb[1 * NS * 4];
         bl[0] = sb[2 * NS * 4];
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < CTN; ++ct) {
         const int rb = ct & 1;
+#if !defined(PCMI_X3_DIAG_NO_BFRAG)
         if (va_cur && ct + 1 < CTN) {
           bh[rb ^ 1] = sb[(0 * NS + 16 * (ct + 1)) * 4];
           bm[rb ^ 1] = sb[(1 * NS + 16 * (ct + 1)) * 4];
           bl[rb ^ 1] = sb[(2 * NS + 16 * (ct + 1)) * 4];
         }
-        // six products, the small ones first.  One wave-uniform branch per column tile (not per MFMA); with both row
-        // groups present their MFMAs alternate (independent accumulators).
+#endif
+        // six products per row group, the small ones first, BACK TO BACK on the group's accumulator, one group after the other
+        // (round 3 alternated the two groups' accumulators: the same sums in the same order per accumulator, 0.6 % slower
+        // in the step -- profiles/r04e_kernel_component_removal.txt); one wave-uniform branch per column tile, not per MFMA
+#if defined(PCMI_X3_DIAG_NO_MFMA)  // timing diagnostic (wrong results): the operands are kept alive, the products are not issued
+#define PCMI_X3_MFMA(G, AT, BT) asm volatile("" ::"v"(AT[G]), "v"(BT[rb]))
+#else
 #define PCMI_X3_MFMA(G, AT, BT)                                                                                             \
   acc[G][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[G]), __builtin_bit_cast(bf16x8, BT[rb]), \
                                                        acc[G][ct], 0, 0, 0)
+#endif
 #define PCMI_X3_SIX(G)      \
   PCMI_X3_MFMA(G, al, bh);  \
   PCMI_X3_MFMA(G, ah, bl);  \
@@ -382,18 +406,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
         } else
 #endif
         if (g0 && g1) {
-          PCMI_X3_MFMA(0, al, bh);
-          PCMI_X3_MFMA(1, al, bh);
-          PCMI_X3_MFMA(0, ah, bl);
-          PCMI_X3_MFMA(1, ah, bl);
-          PCMI_X3_MFMA(0, am, bm);
-          PCMI_X3_MFMA(1, am, bm);
-          PCMI_X3_MFMA(0, am, bh);
-          PCMI_X3_MFMA(1, am, bh);
-          PCMI_X3_MFMA(0, ah, bm);
-          PCMI_X3_MFMA(1, ah, bm);
-          PCMI_X3_MFMA(0, ah, bh);
-          PCMI_X3_MFMA(1, ah, bh);
+          PCMI_X3_SIX(0);
+          PCMI_X3_SIX(1);
         } else if (g0) {
           PCMI_X3_SIX(0);
         } else if (g1) {
@@ -402,21 +416,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
 #undef PCMI_X3_SIX
 #undef PCMI_X3_MFMA
         // the next step's operands, requested in the shadow of this step's MFMAs
-#if defined(PCMI_X3_EARLY_B)
-        // A/B build (libpcmi_earlyb.so): the weight block of the next step is requested behind the FIRST column tile
-        // (its look-up was staged at the end of the step before), the gathers behind the second
-        if (ct == 0) stage_b(more, (step + 1) & 1);
-        if (ct == 1) va_nxt = stage_a(nxt, more);
-        if (ct == CTN - 1) stage_meta();
-#else
         if (ct == 0) stage_meta();
         if (ct == 1) stage_b(more, (step + 1) & 1);
         if (ct == 2) va_nxt = stage_a(nxt, more);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if (more) store_b((step + 1) & 1);
+#if defined(PCMI_X3_DIAG_NO_BARRIER)  // timing diagnostic (racy): the waves of a workgroup never meet
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
       __syncthreads();
+#endif
     };
     for (int step = 0; step < nsteps; step += 2) {
       do_step(step, a0, va0, a1, va1);
