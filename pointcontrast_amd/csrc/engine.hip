@@ -443,6 +443,9 @@ struct BackwardRun {
     if (op.type == PCMI_OP_CONV) {
       const pcmi_kmap_t* map = ps->has_map[i] ? &ps->maps[i] : nullptr;
       // dy is complete at this point of `st` (all its consumers were differentiated before)
+      // (weight gradients of the largest layers ON the chain instead of the side stream -- they cannot share a CU with the
+      //  chain's kernels anyway, two of their workgroups fill register file and LDS -- were measured: 16.47 against 15.85 ms
+      //  per step with the 175k-row layers in the chain, 17.1 with everything from 8000 rows: profiles/r04i_*)
       PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
       PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[0], 0));
       side_pending = side_used = true;
