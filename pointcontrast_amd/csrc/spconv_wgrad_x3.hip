@@ -197,6 +197,273 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
   }
 }
 
+// ---- producer / consumer form (round 4) -------------------------------------------------------------------------------
+// wgrad_x3t_kernel above stages and multiplies with the SAME four waves: gather (8 loads per thread) -> wait -> split -> LDS
+// -> barrier -> MFMAs -> barrier, per (tile, offset).  Timing with components compiled out
+// (profiles/r04e_kernel_component_removal.txt): without the gathers it runs 25 % shorter, without the MFMAs 20 % -- it is
+// bound by the exposed staging phase, and its 248 registers leave no room to request the next unit's rows early (round 3
+// tried: 3 instead of 4 offsets per workgroup, slower).  Here the two jobs belong to different waves of an 8-wave workgroup
+// (one per CU): waves 0-3 only multiply (they own the accumulators), waves 4-7 only stage -- no accumulators, so a producer
+// keeps the rows of THREE units in flight in registers (the gathers of slot q + 3 are issued before slot q + 1 is converted)
+// and writes the packed image of the next unit into the other half of a double-buffered LDS while the consumers multiply
+// the current one.  One workgroup barrier per (tile, offset slot); absent slots cost a barrier and nothing else.
+//   slots   q = tile * KG + s; X(q) lives in s_x[q & 1] (KG is even: = s & 1), G(tile) in s_g[tile & 1]
+//   tables  (row offsets of a tile's KG offsets, the G row offsets, which slots are present) for tile T are loaded by the
+//           producers during tile T - 2 into a ring of three -- visible long before anybody plans with them
+//   step q  producers: [s == 0: request the table of tile + 2] request X(q + 3); convert + write X(q + 1); [s == 1: convert +
+//           write G(tile + 1)]; [s == 2: write the table of tile + 2]; [s == 3: request G(tile + 2)]
+//           consumers: multiply slot q if present      all: barrier
+// Same cells, same fragment reads, same six products in the same order per accumulator, same slabs as wgrad_x3t_kernel: the
+// results are bit-identical to it for the same row-block count.
+template <int MTW, int NTW, int KG>
+__global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
+  static_assert(KG % 2 == 0 && KG >= 2 && KG <= 4, "slot parity = offset parity; one producer wave per offset slot");
+  constexpr int TR = 64, RG = TR / 8;
+  constexpr int CB = 32 * MTW, NB = 32 * NTW;
+  constexpr uint32_t kAbsent = 0x80000000u;
+  constexpr int kRsrcFlags = 0x00020000;
+  __shared__ __attribute__((aligned(16))) u32x4 s_x[2][3 * RG * CB];
+  __shared__ __attribute__((aligned(16))) u32x4 s_g[2][3 * RG * NB];
+  __shared__ uint32_t s_xoff[3][KG][TR];
+  __shared__ uint32_t s_goff[3][TR];
+  __shared__ int s_any[3][KG];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool producer = wave >= 4;
+  const int b = blockIdx.x;
+  // RB a multiple of 8: the groups of a row block share an XCD (as wgrad_x3t_kernel); otherwise plain row-block-major
+  const int og = (a.RB % 8 == 0) ? (b >> 3) % a.NG : b % a.NG;
+  const int rb = (a.RB % 8 == 0) ? (b & 7) + 8 * (b / (8 * a.NG)) : b / a.NG;
+  const int kbase = og * KG;
+  const int c0 = blockIdx.y * CB, n0 = blockIdx.z * NB;
+  const int n_tiles = (int)((a.n_rows + TR - 1) / TR);
+  const int t0 = rb * a.tiles_per_rb, t1 = min(t0 + a.tiles_per_rb, n_tiles);
+  const int nt_tiles = max(t1 - t0, 0);
+  const uint32_t xld = (uint32_t)(a.x_ld * 4), gld = (uint32_t)(a.g_ld * 4);
+
+  if (producer) {
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7FFFFFFF, kRsrcFlags);
+    const int pt = t - 256, rg_s = pt & 7, q_s = pt >> 3;  // staging task: row group x channel quad (as wgrad_x3t_kernel)
+    // tables of relative tile `tl` (tile t0 + tl; past the range: everything absent) into ring slot tl % 3, in two halves:
+    // the global loads are issued in one step and their results written to LDS two steps later, so that the producer
+    // never waits for a table entry it has just requested (wave 4 + sx looks after offset slot sx; wave 4 also after G)
+    int32_t tab_v[(KG + 3) / 4];
+    int32_t tab_g = -1;
+    auto table_issue = [&](int tl) {
+      const int64_t p0 = (int64_t)(t0 + tl) * TR;
+      const bool in_range = tl < nt_tiles;
+      const int64_t pos = p0 + lane;
+#pragma unroll
+      for (int j = 0; j < (KG + 3) / 4; ++j) {
+        const int sx = wave - 4 + 4 * j, k = kbase + sx;
+        tab_v[j] = -1;
+        if (sx < KG && in_range && k < a.K && pos < a.n_rows) tab_v[j] = a.nbr[(int64_t)k * a.n_rows + pos];
+      }
+      // (unconditional reset + ONE guarded load: a reset inside `if (wave == 4)` becomes a select on the register's old
+      //  value -- the result of the load two tiles ago as far as the compiler knows -- and with it an s_waitcnt vmcnt(0))
+      tab_g = -1;
+      if (wave == 4 && in_range && pos < a.n_rows) tab_g = a.perm ? a.perm[pos] : (int32_t)pos;
+    };
+    auto table_commit = [&](int tl) {
+      const int sl = tl % 3;
+#pragma unroll
+      for (int j = 0; j < (KG + 3) / 4; ++j) {
+        const int sx = wave - 4 + 4 * j;
+        if (sx < KG) {
+          s_xoff[sl][sx][lane] = tab_v[j] >= 0 ? (uint32_t)tab_v[j] * xld : kAbsent;
+          const bool any = __ballot(tab_v[j] >= 0) != 0ull;
+          if (lane == 0) s_any[sl][sx] = any ? 1 : 0;
+        }
+      }
+      if (wave == 4) s_goff[sl][lane] = tab_g >= 0 ? (uint32_t)tab_g * gld : kAbsent;
+    };
+    // (no branch around the loads or the conversion: a thread without a task -- 24 channel quads x 8 row groups = 192 of
+    //  the 256 producer threads at 96 channels -- requests out of range and only skips the LDS writes.  A guarded request is
+    //  a path on which it was never issued, and the compiler then counts the OTHER register set's loads as the youngest:
+    //  it converted the rows of slot q + 1 behind s_waitcnt vmcnt(0), i.e. behind the gathers of slot q + 2.)
+    auto issue = [&](v4f (&v)[8], const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, int width) {
+      // (a thread without a task adds 2^31 instead of its column: out of range for every present row -- an absent row
+      //  wraps to offset 0 and reads a few bytes nobody uses; a select AROUND the table read became two load paths)
+#if defined(PCMI_X3_DIAG_NO_GATHER)  // timing diagnostic (wrong results): every row out of range = no memory traffic
+      const uint32_t col = kAbsent + ((uint32_t)(ch0 + width) & 0u);
+#else
+      const uint32_t col = q_s < width / 4 ? (uint32_t)(ch0 + 4 * q_s) * 4u : kAbsent;
+#endif
+#pragma unroll
+      for (int e = 0; e < 8; ++e)  // an absent row has an offset >= 2^31: out of range, the load returns zeros
+#if defined(PCMI_X3_DIAG_NO_GATHER)
+        v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (offs[8 * rg_s + e] & 0xFFFFu) | col, 0, 0));
+#else
+        v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offs[8 * rg_s + e] + col, 0, 0));
+#endif
+    };
+    auto finish = [&](u32x4* dst, const v4f (&v)[8], int width) {
+      const bool active = q_s < width / 4;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const v4f x0 = {v[0][e4], v[1][e4], v[2][e4], v[3][e4]}, x1 = {v[4][e4], v[5][e4], v[6][e4], v[7][e4]};
+        u32x4 h, m, l;
+#if defined(PCMI_X3_DIAG_NO_SPLIT)  // timing diagnostic (wrong results)
+        h = __builtin_bit_cast(u32x4, x0); m = __builtin_bit_cast(u32x4, x1); l = h;
+#else
+        split3(x0, x1, h, m, l);
+#endif
+#if defined(PCMI_X3_DIAG_NO_LDSW)  // timing diagnostic (wrong results): the packed cells are not written
+        asm volatile("" ::"v"(h), "v"(m), "v"(l));
+        if (false) {
+#else
+        if (active) {
+#endif
+          const int cell = rg_s * width + ((4 * q_s + e4) ^ rg_s);
+          dst[cell] = h;
+          dst[RG * width + cell] = m;
+          dst[2 * RG * width + cell] = l;
+        }
+      }
+    };
+    // FOUR register sets for the gathered rows (the producers own no accumulators): the rows of slot q + 3 are requested in
+    // step q and converted in step q + 2 -- two full steps in flight (with two sets / one step the step lasted as long as
+    // a gather under load: 0.54 ms per level-0 launch, profiles/r04j_*); slot s of a tile uses set s (KG = 4).  The G rows
+    // of tile + 2 are requested in a tile's last step and converted in the next tile's second.
+    static_assert(KG == 4, "one register set per offset slot");
+    v4f r0[8], r1[8], r2[8], r3[8], rgv[8];
+    // Requests and conversions are UNCONDITIONAL: an absent slot has nothing but out-of-range offsets in its table (no
+    // memory traffic, zeros come back) and is converted like any other -- a few hundred wasted VALU cycles in waves that
+    // have slack.  With the requests under `if (present)` the compiler cannot pair a request with its conversion (two
+    // reads of the same flag), assumes requests that were never consumed and guards every reuse of the ring registers
+    // with s_waitcnt vmcnt(0) -- which exposes the latency of the gathers it has just issued.
+    table_issue(0);
+    table_commit(0);
+    table_issue(1);
+    table_commit(1);
+    __syncthreads();  // (B0) the first two tables are visible
+    issue(r0, xr, s_xoff[0][0], c0, CB);
+    issue(rgv, gr, s_goff[0], n0, NB);
+    issue(r1, xr, s_xoff[0][1], c0, CB);
+    issue(r2, xr, s_xoff[0][2], c0, CB);
+    finish(s_x[0], r0, CB);
+    finish(s_g[0], rgv, NB);
+    issue(rgv, gr, s_goff[1], n0, NB);  // G rows of the second tile (converted in step 1)
+    __syncthreads();  // (B1) slot 0 and the G rows of the first tile are staged
+#define PCMI_X3P_SET(j) ((j) == 0 ? r0 : ((j) == 1 ? r1 : ((j) == 2 ? r2 : r3)))
+    for (int tl = 0; tl < nt_tiles; ++tl) {
+#pragma unroll
+      for (int sx = 0; sx < KG; ++sx) {
+        if (sx == 0) table_issue(tl + 2);
+        {  // rows of slot q + 3 into the register set slot q - 1 has left (converted two steps ago)
+          const int s3 = (sx + 3) % KG, tl3 = tl + (sx + 3) / KG;
+          issue(PCMI_X3P_SET(s3), xr, s_xoff[tl3 % 3][s3], c0, CB);
+        }
+        // slot q + 1 (requested two steps ago): convert and write into the X buffer the consumers are not reading
+        finish(s_x[(sx + 1) & 1], PCMI_X3P_SET((sx + 1) % KG), CB);
+        if (sx == 1) finish(s_g[(tl + 1) & 1], rgv, NB);
+        if (sx == KG - 2) table_commit(tl + 2);  // (first read one step on: a barrier away)
+        if (sx == KG - 1) issue(rgv, gr, s_goff[(tl + 2) % 3], n0, NB);  // (its table: written one step ago)
+        __syncthreads();
+      }
+    }
+#undef PCMI_X3P_SET
+    return;
+  }
+
+  // ---- consumers: waves 0-3, 2 x 2 over the [CB x NB] block, MTW x NTW tiles of 16 x 16 each ---------------------------
+  const int i = lane & 15, kk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4 acc[KG][MTW][NTW];
+#pragma unroll
+  for (int sx = 0; sx < KG; ++sx)
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[sx][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();  // (B0)
+  __syncthreads();  // (B1)
+  for (int tl = 0; tl < nt_tiles; ++tl) {
+    const u32x4* sg = s_g[tl & 1];
+#pragma unroll
+    for (int sx = 0; sx < KG; ++sx) {
+      if (s_any[tl % 3][sx] != 0) {  // (uniform)
+        const u32x4* sxp = s_x[sx & 1];
+        // One consumer wave per SIMD: nobody else covers an LDS round trip, so the fragment reads are pipelined by hand --
+        // the B fragments of column tile nt + 1 (of the next 32-row step behind the last one) are requested before the 18
+        // MFMAs of tile nt are issued, pinned with sched_barrier (left to the compiler: ~18 lgkmcnt(0) waits per unit right
+        // behind their reads, ~2000 stall cycles against 1836 of MFMA issue).  The A fragments of a step stay live across
+        // its column tiles; the second step's are read behind the first step's last tile (no registers to hold both).
+        u32x4 ah[MTW], am[MTW], al[MTW];
+        u32x4 bh[2], bm[2], bl[2];
+        auto read_a = [&](int step) {
+          const int rgq = 4 * step + kk;  // the 8 rows this lane quad contracts in this MFMA
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
+            const int cell = rgq * CB + ((16 * (wm * MTW + mt) + i) ^ rgq);
+            ah[mt] = sxp[cell];
+            am[mt] = sxp[RG * CB + cell];
+            al[mt] = sxp[2 * RG * CB + cell];
+          }
+        };
+        auto read_b = [&](int step, int nt, int slot) {
+          const int rgq = 4 * step + kk;
+          const int cell = rgq * NB + ((16 * (wn * NTW + nt) + i) ^ rgq);
+          bh[slot] = sg[cell];
+          bm[slot] = sg[RG * NB + cell];
+          bl[slot] = sg[2 * RG * NB + cell];
+        };
+        constexpr int STEPS = TR / 32;
+        read_a(0);
+        read_b(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < STEPS * NTW; ++it) {
+          const int step = it / NTW, nt = it % NTW, slot = it & 1;
+          if (it + 1 < STEPS * NTW) read_b((it + 1) / NTW, (it + 1) % NTW, slot ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+#if defined(PCMI_X3_DIAG_NO_MFMA)  // timing diagnostic (wrong results)
+#define PCMI_WX3P_MFMA(AT, BT) asm volatile("" ::"v"(AT[mt]), "v"(BT[slot]))
+#else
+#define PCMI_WX3P_MFMA(AT, BT)                                                                                                      \
+  acc[sx][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[mt]), __builtin_bit_cast(bf16x8, BT[slot]), \
+                                                            acc[sx][mt][nt], 0, 0, 0)
+#endif
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) {
+            PCMI_WX3P_MFMA(al, bh);
+            PCMI_WX3P_MFMA(ah, bl);
+            PCMI_WX3P_MFMA(am, bm);
+            PCMI_WX3P_MFMA(am, bh);
+            PCMI_WX3P_MFMA(ah, bm);
+            PCMI_WX3P_MFMA(ah, bh);
+          }
+#undef PCMI_WX3P_MFMA
+          __builtin_amdgcn_sched_barrier(0);
+          if (nt == NTW - 1 && step + 1 < STEPS) {
+            read_a(step + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- slabs: D[row = 4 kk + r][col = i] of every 16x16 tile; row = input channel, col = output channel ------------
+#pragma unroll
+  for (int sx = 0; sx < KG; ++sx) {
+    const int k = kbase + sx;
+    if (k >= a.K) continue;
+    float* slab = a.slabs + ((int64_t)k * a.RB + rb) * a.C * a.N;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = c0 + 16 * (wm * MTW + mt) + 4 * kk + r, n = n0 + 16 * (wn * NTW + nt) + i;
+          slab[(int64_t)c * a.N + n] = acc[sx][mt][nt][r];
+        }
+  }
+}
+
 // gW[k][e] (+)= sum over the row blocks of slab[k][rb][e], in row-block order.  32 elements x 8 row-block lanes per
 // workgroup, folded through LDS (the chain of dependent loads is RB / 8 long).
 __global__ __launch_bounds__(256) void wgrad_slab_sum_kernel(const float* __restrict__ slabs, int RB, int64_t per_k,
@@ -244,12 +511,19 @@ bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int
          wgrad_x3t_tw(cin) > 0 && wgrad_x3t_tw(cout) > 0 && n_in * in_ld * 4 <= 0x7FFFFF00ll && n_out * gout_ld * 4 <= 0x7FFFFF00ll;
 }
 
-static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz) {
+// PCMI_WGRAD_X3P: 1 = the producer / consumer form (wgrad_x3p_kernel: 8 waves, one workgroup per CU); read per call
+static bool wgrad_x3p_on() {
+  const char* e = getenv("PCMI_WGRAD_X3P");
+  return e ? atoi(e) != 0 : true;
+}
+
+static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz, int per_cu = 2) {
   const int NG = (PCMI_MAX_KERNEL_VOLUME + kWgradTKG - 1) / kWgradTKG;
   const int64_t n_tiles = ceil_div(n_rows, 64);
-  // two resident workgroups per CU (one per CU: 238.6 against 240 pairs/s in the step); one round of them, at least 4
-  // tiles per workgroup, a multiple of 8 row blocks
-  int64_t rb = (int64_t)2 * num_cu() / ((int64_t)NG * gy * gz);
+  // `per_cu` resident workgroups per CU (wgrad_x3t_kernel: two -- one per CU: 238.6 against 240 pairs/s in the step; the
+  // producer / consumer form is one 8-wave workgroup per CU); one round of them, at least 4 tiles per workgroup, a
+  // multiple of 8 row blocks
+  int64_t rb = (int64_t)per_cu * num_cu() / ((int64_t)NG * gy * gz);
   rb = std::min<int64_t>(rb, n_tiles / 4);
   rb = std::max<int64_t>(8, std::min<int64_t>(kWgradTMaxRB, rb / 8 * 8));
   return (int)rb;
@@ -263,8 +537,9 @@ size_t wgrad_x3t_workspace(int64_t n_rows, int cin, int cout) {
 }
 
 template <int MTW, int NTW>
-static void launch_x3t(const WgradTArgs& a, dim3 grid, hipStream_t st) {
-  wgrad_x3t_kernel<MTW, NTW, kWgradTKG><<<grid, 256, 0, st>>>(a);
+static void launch_x3t(const WgradTArgs& a, dim3 grid, bool pc, hipStream_t st) {
+  if (pc) wgrad_x3p_kernel<MTW, NTW, kWgradTKG><<<grid, 512, 0, st>>>(a);
+  else wgrad_x3t_kernel<MTW, NTW, kWgradTKG><<<grid, 256, 0, st>>>(a);
 }
 
 int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gout_ld, int64_t n_rows, int cin, int cout,
@@ -284,17 +559,23 @@ int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gou
   a.N = cout;
   const int gy = cin / (32 * MTW), gz = cout / (32 * NTW);
   a.NG = (map->K + kWgradTKG - 1) / kWgradTKG;
-  a.RB = wgrad_x3t_rb(n_rows, gy, gz);
+  const bool pc = wgrad_x3p_on();
+  a.RB = wgrad_x3t_rb(n_rows, gy, gz, pc ? 1 : 2);
+  if (pc && getenv("PCMI_WGRAD_X3P_FILL")) {  // A/B: as many row blocks as CUs allow, not rounded to a multiple of 8
+    const int NG = (map->K + kWgradTKG - 1) / kWgradTKG;
+    const int64_t want = std::min<int64_t>((int64_t)num_cu() / ((int64_t)NG * gy * gz), ceil_div(n_rows, 64) / 4);
+    if (want > a.RB && want <= wgrad_x3t_rb(n_rows, gy, gz, 2)) a.RB = (int)want;  // (the workspace is sized for the two-per-CU count)
+  }
   a.tiles_per_rb = (int)ceil_div(ceil_div(n_rows, 64), a.RB);
   const size_t need = (size_t)map->K * a.RB * cin * cout * sizeof(float);
   PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "wgrad x3t: workspace %zu < %zu bytes", ws_bytes, need);
   a.slabs = (float*)ws;
   const dim3 grid((unsigned)(a.RB * a.NG), (unsigned)gy, (unsigned)gz);
   switch (MTW * 4 + NTW) {
-    case 3 * 4 + 3: launch_x3t<3, 3>(a, grid, st); break;
-    case 3 * 4 + 2: launch_x3t<3, 2>(a, grid, st); break;
-    case 2 * 4 + 3: launch_x3t<2, 3>(a, grid, st); break;
-    default: launch_x3t<2, 2>(a, grid, st); break;
+    case 3 * 4 + 3: launch_x3t<3, 3>(a, grid, pc, st); break;
+    case 3 * 4 + 2: launch_x3t<3, 2>(a, grid, pc, st); break;
+    case 2 * 4 + 3: launch_x3t<2, 3>(a, grid, pc, st); break;
+    default: launch_x3t<2, 2>(a, grid, pc, st); break;
   }
   PCMI_LAUNCH_CHECK();
   const int64_t per_k = (int64_t)cin * cout;
