@@ -232,9 +232,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool producer = wave >= 4;
   const int b = blockIdx.x;
-  // RB a multiple of 8: the groups of a row block share an XCD (as wgrad_x3t_kernel); otherwise plain row-block-major
-  const int og = (a.RB % 8 == 0) ? (b >> 3) % a.NG : b % a.NG;
-  const int rb = (a.RB % 8 == 0) ? (b & 7) + 8 * (b / (8 * a.NG)) : b / a.NG;
+  const int og = (b >> 3) % a.NG;
+  const int rb = (b & 7) + 8 * (b / (8 * a.NG));
   const int kbase = og * KG;
   const int c0 = blockIdx.y * CB, n0 = blockIdx.z * NB;
   const int n_tiles = (int)((a.n_rows + TR - 1) / TR);
@@ -561,11 +560,10 @@ int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gou
   a.NG = (map->K + kWgradTKG - 1) / kWgradTKG;
   const bool pc = wgrad_x3p_on();
   a.RB = wgrad_x3t_rb(n_rows, gy, gz, pc ? 1 : 2);
-  if (pc && getenv("PCMI_WGRAD_X3P_FILL")) {  // A/B: as many row blocks as CUs allow, not rounded to a multiple of 8
-    const int NG = (map->K + kWgradTKG - 1) / kWgradTKG;
-    const int64_t want = std::min<int64_t>((int64_t)num_cu() / ((int64_t)NG * gy * gz), ceil_div(n_rows, 64) / 4);
-    if (want > a.RB && want <= wgrad_x3t_rb(n_rows, gy, gz, 2)) a.RB = (int)want;  // (the workspace is sized for the two-per-CU count)
-  }
+  // (the producer / consumer form takes 8 x NG x (RB / 8) = 224 of the 256 CUs at NG = 7: with every CU used -- 36 row
+  //  blocks, 252 workgroups -- it is 11 % faster alone (0.501 against 0.560 ms) and SLOWER in the step (253.1-254.6 against
+  //  256.6-256.9 pairs/s): the CUs it leaves are where the backward chain's kernels run meanwhile; fewer row blocks lose
+  //  again -- 24: 254.6, 16: 252.7.  profiles/r04jk_wgrad_producer_consumer.txt)
   a.tiles_per_rb = (int)ceil_div(ceil_div(n_rows, 64), a.RB);
   const size_t need = (size_t)map->K * a.RB * cin * cout * sizeof(float);
   PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "wgrad x3t: workspace %zu < %zu bytes", ws_bytes, need);
