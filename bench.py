@@ -169,7 +169,7 @@ def kernel_rooflines(batch, device, joint=True):
              and min(n_in, n_out) >= int(os.environ.get("PCMI_CONV16", "512")) > 0)
     # ... and the weight gradients of the 3^3 / stride-1 convolutions the tile-stationary kernel takes
     # (csrc/spconv_wgrad_x3.hip: wgrad_x3t_eligible)
-    x3t_rows = int(os.environ.get("PCMI_WGRAD_X3T", "16384"))
+    x3t_rows = int(os.environ.get("PCMI_WGRAD_X3T", "8192"))
     tw = lambda c: c % 96 == 0 or c % 64 == 0
     split = split or (mode == "bwd_weight" and kmap is not None and K == 27 and not transpose and min(cin, cout) >= 64
                       and tw(cin) and tw(cout) and 0 < x3t_rows <= n_out)
@@ -190,7 +190,7 @@ def kernel_rooflines(batch, device, joint=True):
   kname = "spconv16x (bf16x3 split)" if x3_on else "spconv16p (fp32 MFMA)"
   dominant = conv_entry("%s fwd 3^3 96->96 @level1 (%d rows)" % (kname, n), 96, 96, m, 27, n, n)
   conv_entry("%s bwd_data 3^3 96->96 @level1" % kname, 96, 96, m, 27, n, n, mode="bwd_data")
-  conv_entry("wgrad_x3t (bf16x3 split, tile-stationary) 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
+  conv_entry("wgrad_x3p (bf16x3 split, tile-stationary, staging / multiplying waves) 3^3 96->96 @level1", 96, 96, m, 27, n, n, mode="bwd_weight")
   conv_entry("%s fwd 3^3 128->96 @level1" % kname, 128, 96, m, 27, n, n)
   ck = cm.stride(key, 2)
   m2 = cm.kernel_map(key, ck, 2, 2, 0)
@@ -200,7 +200,7 @@ def kernel_rooflines(batch, device, joint=True):
   conv_entry("spconv_mfma pair fwd 2^3/s2^T 96->96 (scatter)", 96, 96, m2, 8, m2.n_out, m2.n_in, transpose=True)
   m1 = cm.kernel_map(ck, ck, 3, 1, 3)
   conv_entry("%s fwd 3^3 32->32 @level2 (%d rows)" % (k32, m2.n_out), 32, 32, m1, 27, m2.n_out, m2.n_out)
-  conv_entry("wgrad_x3t (bf16x3 split, tile-stationary) 3^3 96->96 @level2 (%d rows)" % m2.n_out, 96, 96, m1, 27, m2.n_out, m2.n_out,
+  conv_entry("wgrad_x3p (bf16x3 split, tile-stationary, staging / multiplying waves) 3^3 96->96 @level2 (%d rows)" % m2.n_out, 96, 96, m1, 27, m2.n_out, m2.n_out,
              mode="bwd_weight")
   conv_entry("stem32_fwd 3^3 3->32 @level1 (lane per row)", 3, 32, cm.kernel_map(key, key, 3, 1, 0), 27, n, n)
   # PointInfoNCE block, n = 4096 positives, 32 channels: logits GEMM forward, (recompute + contraction) x 2 backward
@@ -509,7 +509,7 @@ def main():
           return None
         per = pmc["bytes_per_launch"]
         if ent["kernel"].startswith("wgrad"):
-          names, extra = ("wgrad_x3t_kernel<3, 3, 4>", "wgrad_x3t_kernel<3, 3, 8>", "wgrad_mfma_kernel<3, 3, true, true>"), "wgrad_slab_sum_kernel"
+          names, extra = ("wgrad_x3p_kernel<3, 3, 4>", "wgrad_x3t_kernel<3, 3, 4>", "wgrad_mfma_kernel<3, 3, true, true>"), "wgrad_slab_sum_kernel"
         elif ent["kernel"].startswith("spconv16x"):
           names, extra = ("spconv16x_kernel<3, true, true>",), "sk_fixup_kernel"
         else:

@@ -22,6 +22,7 @@
 // one stages while the other multiplies.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "internal.h"
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
   if (producer) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7FFFFFFF, kRsrcFlags);
-    const int pt = t - 256, rg_s = pt & 7, q_s = pt >> 3;  // staging task: row group x channel quad (as wgrad_x3t_kernel)
+    const int pt = t - 256;
     // tables of relative tile `tl` (tile t0 + tl; past the range: everything absent) into ring slot tl % 3, in two halves:
     // the global loads are issued in one step and their results written to LDS two steps later, so that the producer
     // never waits for a table entry it has just requested (wave 4 + sx looks after offset slot sx; wave 4 also after G)
@@ -278,31 +279,41 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
       }
       if (wave == 4) s_goff[sl][lane] = tab_g >= 0 ? (uint32_t)tab_g * gld : kAbsent;
     };
-    // (no branch around the loads or the conversion: a thread without a task -- 24 channel quads x 8 row groups = 192 of
-    //  the 256 producer threads at 96 channels -- requests out of range and only skips the LDS writes.  A guarded request is
-    //  a path on which it was never issued, and the compiler then counts the OTHER register set's loads as the youngest:
-    //  it converted the rows of slot q + 1 behind s_waitcnt vmcnt(0), i.e. behind the gathers of slot q + 2.)
-    auto issue = [&](v4f (&v)[8], const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, int width) {
-      // (a thread without a task adds 2^31 instead of its column: out of range for every present row -- an absent row
-      //  wraps to offset 0 and reads a few bytes nobody uses; a select AROUND the table read became two load paths)
+    // Staging task of a producer thread: row group rg_s (8 consecutive tile rows) x W / 32 consecutive channels -- ALL 256
+    // producer threads have one (with channel quads only 24 x 8 = 192 of them did at 96 channels: the fourth producer wave
+    // idle and the operand split -- what bounds this kernel -- on three SIMDs instead of four).  8 consecutive lanes take the
+    // 8 row groups of the same channels: the LDS write pattern the XOR in the cell address is made for.
+    const int rg_s = pt & 7, q_s = pt >> 3;
+    auto issue = [&](auto& v, const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, auto wtag) {
+      constexpr int W = decltype(wtag)::value, CPT = W / 32;
 #if defined(PCMI_X3_DIAG_NO_GATHER)  // timing diagnostic (wrong results): every row out of range = no memory traffic
-      const uint32_t col = kAbsent + ((uint32_t)(ch0 + width) & 0u);
+      const uint32_t col = kAbsent;
 #else
-      const uint32_t col = q_s < width / 4 ? (uint32_t)(ch0 + 4 * q_s) * 4u : kAbsent;
+      const uint32_t col = (uint32_t)(ch0 + CPT * q_s) * 4u;
 #endif
 #pragma unroll
-      for (int e = 0; e < 8; ++e)  // an absent row has an offset >= 2^31: out of range, the load returns zeros
+      for (int e = 0; e < 8; ++e) {  // an absent row has an offset >= 2^31: out of range, the load returns zeros
 #if defined(PCMI_X3_DIAG_NO_GATHER)
-        v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (offs[8 * rg_s + e] & 0xFFFFu) | col, 0, 0));
+        const uint32_t o = (offs[8 * rg_s + e] & 0xFFFFu) | col;
 #else
-        v[e] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offs[8 * rg_s + e] + col, 0, 0));
+        const uint32_t o = offs[8 * rg_s + e] + col;
 #endif
+        if constexpr (CPT == 3) {
+          const auto t3 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, o, 0, 0);
+          static_assert(sizeof(t3) >= 12, "b96");
+          __builtin_memcpy(&v[e], &t3, 12);
+        } else {
+          const auto t2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, 0, 0);
+          static_assert(sizeof(t2) == 8, "b64");
+          __builtin_memcpy(&v[e], &t2, 8);
+        }
+      }
     };
-    auto finish = [&](u32x4* dst, const v4f (&v)[8], int width) {
-      const bool active = q_s < width / 4;
+    auto finish = [&](u32x4* dst, const auto& v, auto wtag) {
+      constexpr int W = decltype(wtag)::value, CPT = W / 32;
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        const v4f x0 = {v[0][e4], v[1][e4], v[2][e4], v[3][e4]}, x1 = {v[4][e4], v[5][e4], v[6][e4], v[7][e4]};
+      for (int ec = 0; ec < CPT; ++ec) {
+        const v4f x0 = {v[0].f[ec], v[1].f[ec], v[2].f[ec], v[3].f[ec]}, x1 = {v[4].f[ec], v[5].f[ec], v[6].f[ec], v[7].f[ec]};
         u32x4 h, m, l;
 #if defined(PCMI_X3_DIAG_NO_SPLIT)  // timing diagnostic (wrong results)
         h = __builtin_bit_cast(u32x4, x0); m = __builtin_bit_cast(u32x4, x1); l = h;
@@ -311,23 +322,23 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
 #endif
 #if defined(PCMI_X3_DIAG_NO_LDSW)  // timing diagnostic (wrong results): the packed cells are not written
         asm volatile("" ::"v"(h), "v"(m), "v"(l));
-        if (false) {
 #else
-        if (active) {
+        const int cell = rg_s * W + ((CPT * q_s + ec) ^ rg_s);
+        dst[cell] = h;
+        dst[RG * W + cell] = m;
+        dst[2 * RG * W + cell] = l;
 #endif
-          const int cell = rg_s * width + ((4 * q_s + e4) ^ rg_s);
-          dst[cell] = h;
-          dst[RG * width + cell] = m;
-          dst[2 * RG * width + cell] = l;
-        }
       }
     };
+    struct Row { float f[3]; };  // the (2 or 3) channels of one gathered row
+    constexpr std::integral_constant<int, CB> kWX{};
+    constexpr std::integral_constant<int, NB> kWG{};
     // FOUR register sets for the gathered rows (the producers own no accumulators): the rows of slot q + 3 are requested in
     // step q and converted in step q + 2 -- two full steps in flight (with two sets / one step the step lasted as long as
     // a gather under load: 0.54 ms per level-0 launch, profiles/r04j_*); slot s of a tile uses set s (KG = 4).  The G rows
     // of tile + 2 are requested in a tile's last step and converted in the next tile's second.
     static_assert(KG == 4, "one register set per offset slot");
-    v4f r0[8], r1[8], r2[8], r3[8], rgv[8];
+    Row r0[8], r1[8], r2[8], r3[8], rgv[8];
     // Requests and conversions are UNCONDITIONAL: an absent slot has nothing but out-of-range offsets in its table (no
     // memory traffic, zeros come back) and is converted like any other -- a few hundred wasted VALU cycles in waves that
     // have slack.  With the requests under `if (present)` the compiler cannot pair a request with its conversion (two
@@ -338,13 +349,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
     table_issue(1);
     table_commit(1);
     __syncthreads();  // (B0) the first two tables are visible
-    issue(r0, xr, s_xoff[0][0], c0, CB);
-    issue(rgv, gr, s_goff[0], n0, NB);
-    issue(r1, xr, s_xoff[0][1], c0, CB);
-    issue(r2, xr, s_xoff[0][2], c0, CB);
-    finish(s_x[0], r0, CB);
-    finish(s_g[0], rgv, NB);
-    issue(rgv, gr, s_goff[1], n0, NB);  // G rows of the second tile (converted in step 1)
+    issue(r0, xr, s_xoff[0][0], c0, kWX);
+    issue(rgv, gr, s_goff[0], n0, kWG);
+    issue(r1, xr, s_xoff[0][1], c0, kWX);
+    issue(r2, xr, s_xoff[0][2], c0, kWX);
+    finish(s_x[0], r0, kWX);
+    finish(s_g[0], rgv, kWG);
+    issue(rgv, gr, s_goff[1], n0, kWG);  // G rows of the second tile (converted in step 1)
     __syncthreads();  // (B1) slot 0 and the G rows of the first tile are staged
 #define PCMI_X3P_SET(j) ((j) == 0 ? r0 : ((j) == 1 ? r1 : ((j) == 2 ? r2 : r3)))
     for (int tl = 0; tl < nt_tiles; ++tl) {
@@ -353,13 +364,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
         if (sx == 0) table_issue(tl + 2);
         {  // rows of slot q + 3 into the register set slot q - 1 has left (converted two steps ago)
           const int s3 = (sx + 3) % KG, tl3 = tl + (sx + 3) / KG;
-          issue(PCMI_X3P_SET(s3), xr, s_xoff[tl3 % 3][s3], c0, CB);
+          issue(PCMI_X3P_SET(s3), xr, s_xoff[tl3 % 3][s3], c0, kWX);
         }
         // slot q + 1 (requested two steps ago): convert and write into the X buffer the consumers are not reading
-        finish(s_x[(sx + 1) & 1], PCMI_X3P_SET((sx + 1) % KG), CB);
-        if (sx == 1) finish(s_g[(tl + 1) & 1], rgv, NB);
+        finish(s_x[(sx + 1) & 1], PCMI_X3P_SET((sx + 1) % KG), kWX);
+        if (sx == 1) finish(s_g[(tl + 1) & 1], rgv, kWG);
         if (sx == KG - 2) table_commit(tl + 2);  // (first read one step on: a barrier away)
-        if (sx == KG - 1) issue(rgv, gr, s_goff[(tl + 2) % 3], n0, NB);  // (its table: written one step ago)
+        if (sx == KG - 1) issue(rgv, gr, s_goff[(tl + 2) % 3], n0, kWG);  // (its table: written one step ago)
         __syncthreads();
       }
     }
@@ -499,9 +510,11 @@ static int wgrad_x3t_tw(int c) { return c % 96 == 0 ? 3 : (c % 64 == 0 ? 2 : 0);
 // and in the training step, where it shares the chip with the backward chain (profiles/r03i_bench_ab_x3t_window.txt, 3
 // processes each): rows in [16384, 100000] 248.7-250.3 pairs/s, >= 8192 251.4-252.5, >= 16384 **252.0-252.9** -- at 175k
 // rows it is no faster alone but asks a quarter less of the memory system, which the chain's kernels get.
+// Round 4, with the producer / consumer form (profiles/r04n_*, 2 processes each): >= 100000 rows 256.0, >= 16384 257.9,
+// >= 8192 **258.5**, >= 2048 255.7 pairs/s.
 static int64_t wgrad_x3t_min_rows() {
   const char* e = getenv("PCMI_WGRAD_X3T");
-  return e ? (int64_t)atoll(e) : (int64_t)16384;
+  return e ? (int64_t)atoll(e) : (int64_t)8192;
 }
 
 bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int cin, int cout, int64_t in_ld, int64_t gout_ld) {

@@ -36,7 +36,7 @@ for line in open(os.path.join(src, "pmc_FETCH_SIZE.log")):
     algo[line.split()[2]] = {k: int(v) for k, v in m.items()}
 rows, traffic = [], {}
 for k in F:
-  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "wgrad_x3t", "wgrad_slab", "sk_fixup", "x3_pack", "eltwise_kernel<2>")):
+  if not any(x in k for x in ("spconv_mfma", "spconv16", "wgrad_mfma", "wgrad_x3t", "wgrad_x3p", "wgrad_slab", "sk_fixup", "x3_pack", "eltwise_kernel<2>")):
     continue
   rd = mean(F[k]["FETCH_SIZE"]) * 1024 * f_scale
   wr = mean(W[k]["WRITE_SIZE"]) * 1024 * w_scale if k in W else float("nan")
@@ -65,7 +65,7 @@ try:
   md += ["", "| kernel | LDS conflict cycles / LDS active cycles | waves: issuing | parked (s_waitcnt / barrier) | issue-stalled (matrix pipe / dependencies) |",
          "|---|---|---|---|---|"]
   for k in L:
-    if not any(x in k for x in ("spconv16", "wgrad_mfma", "wgrad_x3t")):
+    if not any(x in k for x in ("spconv16", "wgrad_mfma", "wgrad_x3t", "wgrad_x3p")):
       continue
     c = {name: mean(v) for name, v in L[k].items()}
     wc = max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0)
