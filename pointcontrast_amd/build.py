@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libpcmi.so")
-SOURCES = ["coords.hip", "spconv.hip", "spconv_x3.hip", "spconv_wgrad.hip", "spconv_wgrad_x3.hip", "spconv32r.hip", "norm.hip", "loss.hip", "engine.hip", "sortrows.hip", "widths.hip", "loader.hip", "pairs.hip"]
+SOURCES = ["coords.hip", "spconv.hip", "spconv_x3.hip", "spconv_wgrad.hip", "spconv_wgrad_x3.hip", "spconv32r.hip", "norm.hip", "loss.hip", "nce_x3.hip", "engine.hip", "sortrows.hip", "widths.hip", "loader.hip", "pairs.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mcode-object-version=5",
          "-Wall", "-Wno-unused-function"] + os.environ.get("PCMI_EXTRA_HIPCC_FLAGS", "").split()
 

@@ -73,6 +73,14 @@ size_t wgrad_x3t_workspace(int64_t n_rows, int cin, int cout);
 int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gout_ld, int64_t n_rows, int cin, int cout,
                   const pcmi_kmap_t* map, float* gweight, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
+// nce_x3.hip: PointInfoNCE forward / backward on the bf16 matrix cores (three-term split); c in {16, 32}, q / k contiguous
+// and 16-byte aligned, ws of pcmi_nce_workspace_bytes and 16-byte aligned.  PCMI_NCE_X3=0 keeps the fp32 VALU kernels of loss.hip.
+bool nce_x3_on();
+size_t nce_x3_workspace_bytes(int64_t n);
+int nce_x3_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, float* lse, float* loss, void* ws, hipStream_t st);
+int nce_x3_bwd(const float* q, const float* k, const float* lse, int64_t n, int c, float inv_T, const float* gscale, float* dq,
+               float* dk, void* ws, hipStream_t st);
+
 size_t sort_rows_temp_bytes(int64_t n);
 int sort_rows_by_mask(const int32_t* nbr, int K, int64_t n, int64_t chunk_rows, uint32_t* mask_in, uint32_t* mask_out,
                       int32_t* iota, void* temp, size_t temp_bytes, int32_t* perm, int32_t* nbr_perm, hipStream_t st);

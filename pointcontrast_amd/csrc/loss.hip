@@ -253,15 +253,34 @@ __global__ __launch_bounds__(256) void nce_sum_splits_kernel(const float* __rest
 }
 
 // ---- pdist + argmin ------------------------------------------------------------------------------
-template <int C>
+// TR rows of `a` per workgroup against tiles of TS rows of `b`; a thread holds a 4 x 4 block of distances and the
+// TS / 4 threads that share its rows reduce (min, first arg-min) by shuffles.  The mining of the hardest-contrastive
+// loss is p = 4096 positives against s = 1024 candidates: 64-row tiles are 64 workgroups on a 256-CU chip and 16 tile
+// steps each (58 us); TR = 16, TS = 256 is 256 workgroups and 4 steps.
+template <int C, int ROWS>
+__device__ inline void load_rows_dmajor(const float* __restrict__ m, int64_t n, int64_t r0, float (*s)[ROWS + 4], int t) {
+  for (int e = t; e < ROWS * (C / 4); e += 256) {
+    const int row = e / (C / 4), c4 = e % (C / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < n) v = *reinterpret_cast<const float4*>(m + (r0 + row) * C + c4 * 4);
+    s[c4 * 4 + 0][row] = v.x;
+    s[c4 * 4 + 1][row] = v.y;
+    s[c4 * 4 + 2][row] = v.z;
+    s[c4 * 4 + 3][row] = v.w;
+  }
+}
+
+template <int C, int TR, int TS>
 __global__ __launch_bounds__(256) void pdist_argmin_kernel(const float* __restrict__ a, int64_t p,
                                                            const float* __restrict__ b, int64_t s,
                                                            float* __restrict__ dmin, int32_t* __restrict__ amin) {
-  __shared__ __attribute__((aligned(16))) float sa[C][kTile + 4];
-  __shared__ __attribute__((aligned(16))) float sb[C][kTile + 4];
-  const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-  const int64_t r0 = (int64_t)blockIdx.x * kTile;
-  load_tile_dmajor<C>(a, p, r0, sa, t);
+  static_assert(TR * TS == 64 * 64 && TS >= 64, "256 threads x (4 x 4)");
+  constexpr int LPR = TS / 4;  // lanes sharing a row group (16 or 64: inside one wave)
+  __shared__ __attribute__((aligned(16))) float sa[C][TR + 4];
+  __shared__ __attribute__((aligned(16))) float sb[C][TS + 4];
+  const int t = threadIdx.x, tr = t / LPR, tc = t % LPR;
+  const int64_t r0 = (int64_t)blockIdx.x * TR;
+  load_rows_dmajor<C, TR>(a, p, r0, sa, t);
   float best[4];
   int32_t bidx[4];
 #pragma unroll
@@ -269,9 +288,9 @@ __global__ __launch_bounds__(256) void pdist_argmin_kernel(const float* __restri
     best[i] = INFINITY;
     bidx[i] = 0x7fffffff;
   }
-  for (int64_t c0 = 0; c0 < s; c0 += kTile) {
+  for (int64_t c0 = 0; c0 < s; c0 += TS) {
     __syncthreads();
-    load_tile_dmajor<C>(b, s, c0, sb, t);
+    load_rows_dmajor<C, TS>(b, s, c0, sb, t);
     __syncthreads();
     float acc[4][4];
 #pragma unroll
@@ -305,7 +324,7 @@ __global__ __launch_bounds__(256) void pdist_argmin_kernel(const float* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
+    for (int d = 1; d < LPR; d <<= 1) {
       const float ob = __shfl_xor(best[i], d, 64);
       const int32_t oi = __shfl_xor(bidx[i], d, 64);
       if (ob < best[i] || (ob == best[i] && oi < bidx[i])) {
@@ -525,52 +544,115 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t src_ld
       *reinterpret_cast<const float4*>(src + idx[r] * src_ld + col * 4);
 }
 
-// dst[idx[r]] += src[r] WITHOUT float atomics (idx may repeat: two positives matched to the same row): one wave per source
-// row; it owns dst[idx[r]] if no earlier row has the same index and then adds the rows with that index in increasing r
-// (lane = column).  n^2 / 64 wave steps over the index array (L1-resident at the loss's n = 4096 .. 8192).
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t src_ld,
-                                                               const int64_t* __restrict__ idx, int64_t n, int c,
-                                                               float* __restrict__ dst, int64_t dst_ld) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n) return;  // (wave-uniform)
-  const int64_t target = idx[r];
-  // the scans read kScanU x 64 indices per step, all loads issued before the first use (one L2 latency per step: a
-  // load per step made this kernel 24 us at n = 4096)
-  constexpr int kScanU = 8;
-  bool dup = false;
-  for (int64_t b = 0; b < r; b += 64 * kScanU) {
-    int64_t v[kScanU];
+// ---- rows of a list grouped by a key, without sorting and without float atomics -----------------------------------
+// (scatter_add_rows_kernel: rows sharing a destination.)
+// The first row with a key OWNS the group and adds the later rows' contributions in increasing row order, so the sum does
+// not depend on the order the hardware would retire atomics in (the step is bit-reproducible, tests/test_gpu_fullsize.py).
+// Every row has to see every key: a workgroup stages the keys through LDS (kGroupPass per pass) and each of its four
+// waves compares a staged key with the keys of FOUR rows at once -- n / 64 LDS reads per wave and pass, where the first
+// form of this kernel spent n / 64 global loads PER ROW (the same 13 us at n = 4096, but growing with n^2: 4 x per
+// doubling against 2 x here).  hardest_gsub_kernel keeps the per-row form: its groups are few and large (hundreds of
+// positives share a popular negative), the owner's arithmetic is what it waits for, and the staged form measured
+// slower there (79 against 45 us, profiles/r04n_*).
+constexpr int kGroupRows = 16;    // rows per workgroup (4 per wave)
+constexpr int kGroupPass = 4096;  // keys staged per pass
+
+// One staged pass [p0, p0 + len): for wave-row q (row r0 + q, key target[q]) sets dup[q] if an earlier row has the key and
+// collects the later rows that have it, in increasing order, in the wave's list q; a full list -- and, from the caller,
+// whatever is left at the end -- goes to consume(q, rows, count), which fetches the rows' contributions with all its
+// loads in flight and adds them in list order (not a chain of dependent round trips when a group is large).  s_keys holds kGroupPass entries (the ones past the list's end never equal a target).
+constexpr int kListCap = 64;
+template <class Key, class Consume>
+__device__ __forceinline__ void scan_same_key(const Key* __restrict__ s_keys, int len, int64_t p0, int64_t r0,
+                                              const Key (&target)[4], bool (&dup)[4], int (&cnt)[4],
+                                              int32_t (*list)[kListCap], int lane, Consume&& consume) {
+  for (int b4 = 0; b4 < len; b4 += 256) {
+    Key v4[4];  // four LDS reads in flight (the entries past `len` are staged and never match)
 #pragma unroll
-    for (int u = 0; u < kScanU; ++u) {
-      const int64_t j = b + u * 64 + lane;
-      v[u] = j < r ? idx[j] : -1 - target;  // (never equal to target)
-    }
+    for (int u = 0; u < 4; ++u) v4[u] = s_keys[b4 + u * 64 + lane];
 #pragma unroll
-    for (int u = 0; u < kScanU; ++u) dup |= v[u] == target;
-  }
-  if (__any(dup)) return;
-  for (int c0 = 0; c0 < c; c0 += 64) {
-    const int col = c0 + lane;
-    float sum = col < c ? src[r * src_ld + col] : 0.f;
-    for (int64_t b = r + 1; b < n; b += 64 * kScanU) {
-      int64_t v[kScanU];
+    for (int u = 0; u < 4; ++u) {
+      const Key v = v4[u];
+      const int64_t j0 = p0 + b4 + u * 64;
 #pragma unroll
-      for (int u = 0; u < kScanU; ++u) {
-        const int64_t j = b + u * 64 + lane;
-        v[u] = j < n ? idx[j] : -1 - target;
-      }
-#pragma unroll
-      for (int u = 0; u < kScanU; ++u) {
-        uint64_t m = __ballot(v[u] == target);
-        while (m) {  // (rare: rows sharing a destination, in increasing row order)
-          const int64_t jj = b + u * 64 + __builtin_ctzll(m);
-          m &= m - 1;
-          if (col < c) sum += src[jj * src_ld + col];
+      for (int q = 0; q < 4; ++q) {
+        if (dup[q]) continue;  // (wave-uniform) not the owner, or no row at all: nothing left to find out, nothing to add
+        uint64_t m = __ballot(v == target[q]);
+        if (m == 0) continue;  // (wave-uniform; the common case)
+        const int64_t r = r0 + q;
+        if (j0 < r) {  // matches in front of the row: it is not the owner
+          const uint64_t before = r - j0 >= 64 ? ~0ull : ((1ull << (r - j0)) - 1ull);
+          if (m & before) dup[q] = true;
+        }
+        if (!dup[q] && j0 + 63 > r) {  // matches behind it
+          const uint64_t upto = r < j0 ? 0ull : (r - j0 >= 63 ? ~0ull : ((2ull << (r - j0)) - 1ull));  // bits <= r
+          m &= ~upto;
+          while (m) {
+            if (lane == 0) list[q][cnt[q]] = (int32_t)(j0 + __builtin_ctzll(m));
+            m &= m - 1;
+            if (++cnt[q] == kListCap) {
+              consume(q, list[q], kListCap);
+              cnt[q] = 0;
+            }
+          }
         }
       }
     }
-    if (col < c) dst[target * dst_ld + col] += sum;
+  }
+}
+
+// dst[idx[r]] += src[r] (idx may repeat: two positives matched to the same row); lane = column.  See scan_same_key.
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t src_ld,
+                                                               const int64_t* __restrict__ idx, int64_t n, int c,
+                                                               float* __restrict__ dst, int64_t dst_ld) {
+  __shared__ int64_t s_idx[kGroupPass];
+  __shared__ int32_t s_list[4][4][kListCap];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * kGroupRows + wave * 4;
+  int64_t target[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) target[q] = r0 + q < n ? idx[r0 + q] : -1;
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int col = c0 + lane;
+    float sum[4], old[4];
+    bool dup[4];
+    int cnt[4] = {0, 0, 0, 0};
+    auto consume = [&](int q, const int32_t* rows, int m) {
+      constexpr int B = 16;
+      for (int k0 = 0; k0 < m; k0 += B) {
+        float a[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) a[u] = col < c ? src[(int64_t)rows[min(k0 + u, m - 1)] * src_ld + col] : 0.f;
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+          if (k0 + u < m) sum[q] += a[u];
+      }
+    };
+    // every global access this row block needs is requested up front (the kernel is a chain of memory round trips, not
+    // of instructions): own rows, the destination rows (read-modify-write), the first pass of the index array
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool live = r0 + q < n && col < c;
+      sum[q] = live ? src[(r0 + q) * src_ld + col] : 0.f;
+      old[q] = live ? dst[target[q] * dst_ld + col] : 0.f;
+      dup[q] = r0 + q >= n;
+    }
+    for (int64_t p0 = 0; p0 < n; p0 += kGroupPass) {
+      int64_t stage[kGroupPass / 256];
+#pragma unroll
+      for (int u = 0; u < kGroupPass / 256; ++u) stage[u] = p0 + u * 256 + t < n ? idx[p0 + u * 256 + t] : -2;  // (-2: never a target)
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < kGroupPass / 256; ++u) s_idx[u * 256 + t] = stage[u];
+      __syncthreads();
+      scan_same_key(s_idx, (int)min((int64_t)kGroupPass, n - p0), p0, r0, target, dup, cnt, s_list[wave], lane, consume);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (cnt[q]) consume(q, s_list[wave][q], cnt[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!dup[q] && col < c) dst[target[q] * dst_ld + col] = old[q] + sum[q];
   }
 }
 
@@ -709,7 +791,7 @@ int pcmi_scatter_add_rows(const float* src, int64_t src_ld, const int64_t* idx, 
                           int64_t dst_ld, pcmi_stream_t stream) {
   PCMI_REQUIRE(src && idx && dst && c > 0, PCMI_ERR_INVALID, "scatter_add_rows: bad argument");
   if (n == 0) return PCMI_OK;
-  scatter_add_rows_kernel<<<dim3((unsigned)ceil_div(n, 4)), 256, 0, as_stream(stream)>>>(src, src_ld, idx, n, c, dst, dst_ld);
+  scatter_add_rows_kernel<<<dim3((unsigned)ceil_div(n, kGroupRows)), 256, 0, as_stream(stream)>>>(src, src_ld, idx, n, c, dst, dst_ld);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -731,8 +813,9 @@ extern "C" {
 size_t pcmi_nce_workspace_bytes(int64_t n, int c) {
   const size_t sp = 32;  // upper bound of nce_splits
   // forward: 3 x [splits][n] + the block partials; backward: [splits][n][c] per operand
-  return std::max(sp * (size_t)n * 3 * sizeof(float), sp * (size_t)n * c * sizeof(float)) +
-         (size_t)(ceil_div(n, 256) + 1) * sizeof(float) + 1024;
+  const size_t valu = std::max(sp * (size_t)n * 3 * sizeof(float), sp * (size_t)n * c * sizeof(float)) +
+                      (size_t)(ceil_div(n, 256) + 1) * sizeof(float) + 1024;
+  return std::max(valu, nce_x3_workspace_bytes(n));
 }
 
 int pcmi_nce_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, float* lse, float* loss, void* ws,
@@ -742,6 +825,7 @@ int pcmi_nce_fwd(const float* q, const float* k, int64_t n, int c, float inv_T, 
   PCMI_REQUIRE(ws && ws_bytes >= pcmi_nce_workspace_bytes(n, c), PCMI_ERR_WORKSPACE, "nce_fwd: workspace too small");
   PCMI_REQUIRE((uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0, PCMI_ERR_INVALID, "nce_fwd: q/k must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
+  if (nce_x3_on()) return nce_x3_fwd(q, k, n, c, inv_T, lse, loss, ws, st);  // matrix-core form (nce_x3.hip)
   const int nb = (int)ceil_div(n, kTile), splits = nce_splits(n), nb2 = (int)ceil_div(n, 256);
   const int64_t span = nce_span(n, splits);
   float* pm = (float*)ws;
@@ -768,6 +852,11 @@ int pcmi_nce_bwd(const float* q, const float* k, const float* lse, int64_t n, in
   const int64_t span = nce_span(n, splits);
   PCMI_REQUIRE(splits == 1 || (ws && ws_bytes >= pcmi_nce_workspace_bytes(n, c)), PCMI_ERR_WORKSPACE, "nce_bwd: workspace too small");
   PCMI_REQUIRE((uintptr_t)dq % 16 == 0 && (uintptr_t)dk % 16 == 0, PCMI_ERR_INVALID, "nce_bwd: dq/dk must be 16-byte aligned");
+  if (nce_x3_on()) {
+    PCMI_REQUIRE(ws && ws_bytes >= pcmi_nce_workspace_bytes(n, c) && (uintptr_t)q % 16 == 0 && (uintptr_t)k % 16 == 0,
+                 PCMI_ERR_WORKSPACE, "nce_bwd: workspace too small (pcmi_nce_workspace_bytes) or q/k not 16-byte aligned");
+    return nce_x3_bwd(q, k, lse, n, c, inv_T, gscale, dq, dk, ws, st);
+  }
   const dim3 grid((unsigned)nb, (unsigned)splits);
   const int64_t n4 = n * c / 4;
   for (int which = 0; which < 2; ++which) {  // 0: dq, 1: dk
@@ -791,10 +880,14 @@ int pcmi_pdist_argmin(const float* a, int64_t p, const float* b, int64_t s, int 
   PCMI_REQUIRE(a && b && dmin && amin && p > 0 && s > 0, PCMI_ERR_INVALID, "pdist_argmin: bad argument");
   PCMI_REQUIRE(c == 16 || c == 32 || c == 64, PCMI_ERR_UNSUPPORTED, "pdist_argmin: feature width %d not in {16,32,64}", c);
   hipStream_t st = as_stream(stream);
-  const int nb = (int)ceil_div(p, kTile);
-  if (c == 16) pdist_argmin_kernel<16><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
-  if (c == 32) pdist_argmin_kernel<32><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
-  if (c == 64) pdist_argmin_kernel<64><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  // 16-row tiles when 64-row tiles would leave most of the chip without a workgroup (and the candidate tile fits the LDS)
+  const bool narrow = c <= 32 && ceil_div(p, 64) < 2 * (int64_t)num_cu() && s > 64;
+  const int nb = (int)ceil_div(p, narrow ? 16 : 64);
+  if (c == 16 && narrow) pdist_argmin_kernel<16, 16, 256><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  if (c == 16 && !narrow) pdist_argmin_kernel<16, 64, 64><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  if (c == 32 && narrow) pdist_argmin_kernel<32, 16, 256><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  if (c == 32 && !narrow) pdist_argmin_kernel<32, 64, 64><<<nb, 256, 0, st>>>(a, p, b, s, dmin, amin);
+  if (c == 64) pdist_argmin_kernel<64, 64, 64><<<(unsigned)ceil_div(p, 64), 256, 0, st>>>(a, p, b, s, dmin, amin);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

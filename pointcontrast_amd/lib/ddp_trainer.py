@@ -145,6 +145,26 @@ class ContrastiveLossTrainer:
     st[slot] = (buf, ev)
     return out.view(idx_cpu.shape)
 
+  def _upload_any(self, t_cpu, slot):
+    """A small host vector of any dtype -> device through a persistent pinned staging buffer (see _upload)."""
+    st = getattr(self, "_staging_any", None)
+    if st is None:
+      st = self._staging_any = {}
+    n = t_cpu.numel()
+    buf, ev = st.get(slot, (None, None))
+    if buf is None or buf.numel() < n or buf.dtype != t_cpu.dtype:
+      # 25 % head-room (as the device workspace below): the buffer converges after a few batches instead of being
+      # re-pinned -- milliseconds per hipHostMalloc, on the preparation path -- at every new maximum
+      buf, ev = torch.empty(int(n * 1.25) + 8192, dtype=t_cpu.dtype).pin_memory(), None
+    if ev is not None:
+      ev.synchronize()
+    buf[:n].copy_(t_cpu.reshape(-1))
+    out = buf[:n].to(self.cur_device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st[slot] = (buf, ev)
+    return out
+
   # -- shared pieces of one iteration ----------------------------------------------------------
   # A batch is *prepared* (uploads, coordinate hash / levels / kernel maps on the plan stream, host-side index
   # selection) independently of the network state, so with misc.prefetch the next batch is prepared right after
@@ -362,14 +382,10 @@ class ContrastiveLossTrainer:
 
 class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
 
-  def contrastive_hardest_negative_loss(self, F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048,
-                                        draws=None):
-    """pc/lib/ddp_trainer.py:186-238.  positive_pairs: CPU int tensor / array [P,2].
-    draws: optional dict(sel0, sel1, pos_sel) replacing the np.random.choice calls."""
-    N0, N1 = F0.shape[0], F1.shape[0]
-    pp = positive_pairs.numpy() if torch.is_tensor(positive_pairs) else np.asarray(positive_pairs)
-    P = len(pp)
-    hash_seed = max(N0, N1)
+  @staticmethod
+  def _draw_hardest(N0, N1, P, num_pos, num_hn_samples, draws):
+    """np.random.choice in the reference's order (pc/lib/ddp_trainer.py:198-206): candidates of cloud 0, of cloud 1,
+    positives.  Each call permutes the whole range (350k rows, 840k pairs per 4-pair batch: milliseconds of host time)."""
     draws = draws or {}
     sel0 = draws["sel0"] if "sel0" in draws else np.random.choice(N0, min(N0, num_hn_samples), replace=False)
     sel1 = draws["sel1"] if "sel1" in draws else np.random.choice(N1, min(N1, num_hn_samples), replace=False)
@@ -377,19 +393,97 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
       pos_sel = draws["pos_sel"]
     else:
       pos_sel = np.random.choice(P, num_pos, replace=False) if P > num_pos else None
+    return sel0, sel1, pos_sel
+
+  def _upload_hardest(self, N0, N1, pp, drawn, stream, slot=0, keys=None):
+    """The drawn rows and (unless `keys` has it) the hash set of ALL positive pairs on the device, through pinned staging
+    buffers, on `stream` (None: the current one).  Round 3 had five pageable copies here -- each drains the compute
+    stream before it returns -- and a 50 us insert kernel between the forward pass and the loss."""
+    sel0, sel1, pos_sel = drawn
     sample = pp if pos_sel is None else pp[np.asarray(pos_sel)]
-    dev = F0.device
-    up = lambda a, dt=torch.int64: torch.as_tensor(np.ascontiguousarray(a)).to(dev, dtype=dt, non_blocking=True)
-    sel0_d, sel1_d = up(sel0), up(sel1)
-    pos0_d, pos1_d = up(sample[:, 0]), up(sample[:, 1])
-    pairs_d = up(pp, torch.int32)
+    host = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a)).to(dt)
+    cur = torch.cuda.current_stream(self.cur_device)
+    with torch.cuda.stream(stream if stream is not None else cur):
+      up = lambda a, dt, name: self._upload_any(host(a, dt), ("hardest", name, slot))
+      out = dict(sel0=up(sel0, torch.int64, "sel0"), sel1=up(sel1, torch.int64, "sel1"),
+                 pos0=up(sample[:, 0], torch.int64, "pos0"), pos1=up(sample[:, 1], torch.int64, "pos1"))
+      held = [out["sel0"], out["sel1"], out["pos0"], out["pos1"]]
+      if keys is None:
+        pairs_d = up(pp.reshape(-1), torch.int32, "pairs").view(-1, 2)
+        keys = PF.PairKeySet(pairs_d, max(N0, N1))
+        held += [pairs_d, keys.buf]
+      out.update(keys=keys, n=(N0, N1), event=None)
+      if stream is not None:
+        out["event"] = torch.cuda.Event()
+        out["event"].record(stream)
+        for t_ in held:
+          t_.record_stream(cur)
+    return out
+
+  def _prepare_loss(self, prep, draws):
+    """What the loss needs besides the features depends on the batch only (pc/lib/ddp_trainer.py:198-213,224-226), so it is
+    started with the rest of the batch preparation: the key set of the positive pairs is built on the planning stream
+    now; the three np.random.choice calls -- the longest host-side item of this trainer's iteration -- run in a helper
+    thread (numpy's shuffle releases the GIL) while this thread enqueues the forward pass, and are joined in front of
+    the loss.  Nothing else touches np.random in between, so the global generator is consumed in the reference's order."""
+    import threading
+    from ..runtime import handle_pool
+    slot = getattr(self, "_slot", 0)
+    self._slot = slot ^ 1  # two sets of staging buffers: a prefetched batch must not overwrite the live one
+    inp = prep["input"]
+    pp = inp["correspondences"]
+    pp = pp.numpy() if torch.is_tensor(pp) else np.asarray(pp)
+    N0, N1 = int(inp["sinput0_C"].shape[0]), int(inp["sinput1_C"].shape[0])
+    plan, cur = handle_pool.plan_stream(self.cur_device), torch.cuda.current_stream(self.cur_device)
+    with torch.cuda.stream(plan):
+      pairs_d = self._upload_any(torch.as_tensor(np.ascontiguousarray(pp.reshape(-1))).to(torch.int32),
+                                 ("hardest", "pairs", slot)).view(-1, 2)
+      keys = PF.PairKeySet(pairs_d, max(N0, N1))
+      pairs_d.record_stream(cur)
+      keys.buf.record_stream(cur)
+    box = {}
+    args = (N0, N1, len(pp), self.config.trainer.num_pos_per_batch * self.batch_size,
+            self.config.trainer.num_hn_samples_per_batch * self.batch_size, draws)
+
+    def work():
+      try:
+        box["drawn"] = self._draw_hardest(*args)
+      except BaseException as e:  # re-raised by the joining thread
+        box["error"] = e
+
+    th = threading.Thread(target=work, name="pcmi-hardest-draws", daemon=True)
+    th.start()
+    prep["hardest"] = dict(thread=th, box=box, keys=keys, n=(N0, N1), pp=pp, slot=slot, plan=plan)
+
+  def _finish_prepared_loss(self, h):
+    h["thread"].join()
+    if "error" in h["box"]:
+      raise h["box"]["error"]
+    return self._upload_hardest(h["n"][0], h["n"][1], h["pp"], h["box"]["drawn"], h["plan"], h["slot"], keys=h["keys"])
+
+  def contrastive_hardest_negative_loss(self, F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048,
+                                        draws=None, prepared=None):
+    """pc/lib/ddp_trainer.py:186-238.  positive_pairs: CPU int tensor / array [P,2].
+    draws: optional dict(sel0, sel1, pos_sel) replacing the np.random.choice calls.
+    prepared: the samples / key set of _prepare_loss (then positive_pairs, num_*, draws are not looked at)."""
+    N0, N1 = F0.shape[0], F1.shape[0]
+    if prepared is None:
+      if not hasattr(self, "cur_device"):  # (a bare instance, as the parity tests make one)
+        self.cur_device = F0.device
+      pp = positive_pairs.numpy() if torch.is_tensor(positive_pairs) else np.asarray(positive_pairs)
+      prepared = self._upload_hardest(N0, N1, pp, self._draw_hardest(N0, N1, len(pp), num_pos, num_hn_samples, draws), None)
+    elif "thread" in prepared:
+      prepared = self._finish_prepared_loss(prepared)
+    assert prepared["n"] == (N0, N1), "hardest samples were drawn for %s rows, the features have %s" % (prepared["n"], (N0, N1))
+    if prepared.get("event") is not None:  # uploads + key set ran on the planning stream (_prepare_loss)
+      torch.cuda.current_stream(F0.device).wait_event(prepared["event"])
+    sel0_d, sel1_d, pos0_d, pos1_d, keys = (prepared[k] for k in ("sel0", "sel1", "pos0", "pos1", "keys"))
 
     subF0, subF1 = PF.GatherRowsFunction.apply(F0, sel0_d), PF.GatherRowsFunction.apply(F1, sel1_d)
     posF0, posF1 = PF.GatherRowsFunction.apply(F0, pos0_d), PF.GatherRowsFunction.apply(F1, pos1_d)
     with torch.no_grad():
       D01min, D01ind = PF.pdist_argmin(posF0, subF1)
       D10min, D10ind = PF.pdist_argmin(posF1, subF0)
-      keys = PF.PairKeySet(pairs_d, hash_seed)
       neg1 = sel1_d[D01ind.long()]  # row of F1 mined for each posF0
       neg0 = sel0_d[D10ind.long()]
       mask0 = keys.absent(pos0_d, neg1)
@@ -402,19 +496,27 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
   def _train_iter(self, data_loader_iter, timers, draws=None):
     self.model.train()
     data_meter, data_timer, total_timer = timers
+    mark = self._host_mark
+    mark(None)
     self.optimizer.zero_grad()
     total_timer.tic()
     prep, data_time = self._next_prepared(data_loader_iter, data_timer, draws)
     self._prefetch_start(data_loader_iter, draws)
+    mark("next_prepared")
     F0, F1 = self._forward_pair(prep)
+    mark("forward")
     pos_loss, neg_loss = self.contrastive_hardest_negative_loss(
         F0, F1, prep["input"]["correspondences"],
         num_pos=self.config.trainer.num_pos_per_batch * self.batch_size,
-        num_hn_samples=self.config.trainer.num_hn_samples_per_batch * self.batch_size, draws=draws)
+        num_hn_samples=self.config.trainer.num_hn_samples_per_batch * self.batch_size, draws=draws,
+        prepared=prep.get("hardest"))
     loss = pos_loss + neg_loss
+    mark("loss")
     result = self._backward_and_step(loss, {"loss": loss.detach(), "pos_loss": pos_loss.detach(),
                                             "neg_loss": neg_loss.detach()})
+    mark("backward_step")
     self._prefetch(data_loader_iter, draws)
+    mark("prefetch")
     total_timer.toc()
     data_meter.update(data_time)
     return result
@@ -459,26 +561,6 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
       si = torch.as_tensor(np.asarray(si)).long()
       q_unique, k_sel = q_unique[si], k_sel[si]
     return q_unique, k_sel
-
-  def _upload_any(self, t_cpu, slot):
-    """A small host vector of any dtype -> device through a persistent pinned staging buffer (see _upload)."""
-    st = getattr(self, "_staging_any", None)
-    if st is None:
-      st = self._staging_any = {}
-    n = t_cpu.numel()
-    buf, ev = st.get(slot, (None, None))
-    if buf is None or buf.numel() < n or buf.dtype != t_cpu.dtype:
-      # 25 % head-room (as the device workspace below): the buffer converges after a few batches instead of being
-      # re-pinned -- milliseconds per hipHostMalloc, on the preparation path -- at every new maximum
-      buf, ev = torch.empty(int(n * 1.25) + 8192, dtype=t_cpu.dtype).pin_memory(), None
-    if ev is not None:
-      ev.synchronize()
-    buf[:n].copy_(t_cpu.reshape(-1))
-    out = buf[:n].to(self.cur_device, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    st[slot] = (buf, ev)
-    return out
 
   def select_pairs_device(self, pos_pairs, npos, draws=None, slot=0, defer_wait=False):
     """select_pairs with the run detection and the gathers on the device (csrc/pairs.hip): the host keeps what consumes
