@@ -98,6 +98,87 @@ struct RedFinal {
   int out_seg_stride;
 };
 
+// The merge of the per-block partials of one statistics launch (one segment), by ONE workgroup, in a fixed order ->
+// deterministic.  Two levels, in the geometry of the main pass: thread (rl, col) folds the blocks rl, rl + rp, ... of its
+// four channels (coalesced float4 loads, independent of each other), then the c4 column threads fold the rp lanes
+// through LDS.  (A thread-per-channel loop over all blocks was one L2 latency per block: 20 us for 80 blocks.)
+// All 256 threads call; threads t < c4 return the result: MODE 0 (a, b, cnt) = (mean, M2, rows), MODE 1 (sum a, sum b).
+template <int MODE>
+__device__ __forceinline__ void colreduce_merge(const float* __restrict__ part, int nblocks, int64_t n, int rows_per_block,
+                                                int c4, int rp, int t, float4* s_a, float4* s_b, float* s_n, float4& a,
+                                                float4& b, float& cnt) {
+  const int col = t % c4, rl = t / c4;
+  const int c = c4 * 4;
+  cnt = 0.f;
+  a = make_float4(0.f, 0.f, 0.f, 0.f);  // MODE 0: running mean, MODE 1: sum a
+  b = a;                                 // MODE 0: running M2,   MODE 1: sum b
+  if (rl < rp) {
+#pragma unroll 4
+    for (int q = rl; q < nblocks; q += rp) {
+      const float4 pa = *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + col * 4);
+      const float4 pb = *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + c + col * 4);
+      if (MODE == 0) {
+        const int64_t b0 = (int64_t)q * rows_per_block;
+        chan_merge(cnt, a, b, (float)(min(b0 + (int64_t)rows_per_block, n) - b0), pa, pb);
+      } else {
+        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+      }
+    }
+  }
+  __syncthreads();  // (the caller's earlier use of the LDS arrays)
+  s_a[t] = a;
+  s_b[t] = b;
+  s_n[t] = cnt;
+  __syncthreads();
+  if (t >= c4) return;
+  a = s_a[t];
+  b = s_b[t];
+  cnt = s_n[t];
+  for (int q = 1; q < rp; ++q) {
+    const float4 va = s_a[q * c4 + t], vb = s_b[q * c4 + t];
+    if (MODE == 0) {
+      chan_merge(cnt, a, b, s_n[q * c4 + t], va, vb);
+    } else {
+      a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
+      b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+    }
+  }
+}
+
+// MODE 0: (mean, M2, rows) -> invstd / unbiased variance; both: what column thread t of the merging workgroup stores
+__device__ __forceinline__ float4 bn_invstd(const float4& m2, float cnt, float eps) {
+  const float4 var = make_float4(m2.x / cnt, m2.y / cnt, m2.z / cnt, m2.w / cnt);
+  return make_float4(1.0f / sqrtf(var.x + eps), 1.0f / sqrtf(var.y + eps), 1.0f / sqrtf(var.z + eps), 1.0f / sqrtf(var.w + eps));
+}
+template <int MODE>
+__device__ __forceinline__ void colreduce_write(const RedFinal& fin, int t, const float4& a, const float4& b, float cnt) {
+  if (MODE == 0) {
+    const float4 var = make_float4(b.x / cnt, b.y / cnt, b.z / cnt, b.w / cnt);
+    reinterpret_cast<float4*>(fin.save_mean)[t] = a;
+    reinterpret_cast<float4*>(fin.save_invstd)[t] = bn_invstd(b, cnt, fin.eps);
+    const float ub = cnt > 1.f ? cnt / (cnt - 1.f) : 1.f;
+    const float4 unb = make_float4(var.x * ub, var.y * ub, var.z * ub, var.w * ub);
+    if (fin.save_unbiased) reinterpret_cast<float4*>(fin.save_unbiased)[t] = unb;
+    if (fin.running_mean) {
+      float4 rm = reinterpret_cast<float4*>(fin.running_mean)[t], rv = reinterpret_cast<float4*>(fin.running_var)[t];
+      const float mo = fin.momentum, om = 1.f - fin.momentum;
+      rm = make_float4(om * rm.x + mo * a.x, om * rm.y + mo * a.y, om * rm.z + mo * a.z, om * rm.w + mo * a.w);
+      rv = make_float4(om * rv.x + mo * unb.x, om * rv.y + mo * unb.y, om * rv.z + mo * unb.z, om * rv.w + mo * unb.w);
+      reinterpret_cast<float4*>(fin.running_mean)[t] = rm;
+      reinterpret_cast<float4*>(fin.running_var)[t] = rv;
+    }
+  } else {
+    reinterpret_cast<float4*>(fin.out_a)[t] = a;
+    reinterpret_cast<float4*>(fin.out_b)[t] = b;
+    if (fin.acc_a) {
+      float4 ga = reinterpret_cast<float4*>(fin.acc_a)[t], gb = reinterpret_cast<float4*>(fin.acc_b)[t];
+      reinterpret_cast<float4*>(fin.acc_a)[t] = make_float4(ga.x + a.x, ga.y + a.y, ga.z + a.z, ga.w + a.w);
+      reinterpret_cast<float4*>(fin.acc_b)[t] = make_float4(gb.x + b.x, gb.y + b.y, gb.z + b.z, gb.w + b.w);
+    }
+  }
+}
+
 // MODE 0: (sum x, sum x^2) per block -> (mean_b, M2_b)
 // MODE 1: (sum dy_eff, sum dy_eff * xhat)
 template <int MODE>
@@ -213,73 +294,48 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
       reinterpret_cast<float4*>(p0 + c)[t] = sb;
     }
   }
-  // ---- fused final: the last workgroup to arrive merges the per-block partials (fixed order -> deterministic) ----
-  // Two levels, in the geometry of the main pass: thread (rl, col) folds the blocks rl, rl + rp, ... of its four
-  // channels (coalesced float4 loads, independent of each other), then the c4 column threads fold the rp lanes
-  // through LDS.  (A thread-per-channel loop over all blocks was one L2 latency per block: 20 us for 80 blocks.)
+  // ---- fused final: the last workgroup to arrive merges the per-block partials (colreduce_merge) ----
   if (fin.counter == nullptr) return;
   const int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);  // (= gridDim.x for a one-segment launch)
   if (!arrive_last(fin.counter, (unsigned)nblocks, &s_last)) return;
   __shared__ float s_n[256];
-  float cnt = 0.f;
-  a = make_float4(0.f, 0.f, 0.f, 0.f);  // MODE 0: running mean, MODE 1: sum a
-  b = a;                                 // MODE 0: running M2,   MODE 1: sum b
-  if (rl < rp) {
-#pragma unroll 4
-    for (int q = rl; q < nblocks; q += rp) {
-      const float4 pa = *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + col * 4);
-      const float4 pb = *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + c + col * 4);
-      if (MODE == 0) {
-        const int64_t b0 = (int64_t)q * rows_per_block;
-        chan_merge(cnt, a, b, (float)(min(b0 + (int64_t)rows_per_block, n) - b0), pa, pb);
-      } else {
-        a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-        b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
-      }
-    }
-  }
-  s_a[t] = a;
-  s_b[t] = b;
-  s_n[t] = cnt;
-  __syncthreads();
-  if (t >= c4) return;
-  a = s_a[t];
-  b = s_b[t];
-  cnt = s_n[t];
-  for (int q = 1; q < rp; ++q) {
-    const float4 va = s_a[q * c4 + t], vb = s_b[q * c4 + t];
+  float cnt;
+  colreduce_merge<MODE>(part, nblocks, n, rows_per_block, c4, rp, t, s_a, s_b, s_n, a, b, cnt);
+  if (t < c4) colreduce_write<MODE>(fin, t, a, b, cnt);
+}
+
+// The merge of a statistics launch's partials as a launch of its own: one workgroup per segment, the same fold in the
+// same order as the fused form.  Default since round 4: handing the partials to the last-arriving workgroup INSIDE the
+// statistics launch (release, device-scope atomic, acquire, reloads that miss) cost the step 1.48 ms over its 129
+// BatchNorm statistics launches -- 11.5 us each, more than a kernel boundary and this 3 us kernel
+// (profiles/r04p_bn_statistics_hand_over.txt).
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, int64_t n, int c4, int rp,
+                                                              int rows_per_block, RedFinal fin, int64_t seg_split,
+                                                              int64_t part_seg_stride) {
+  __shared__ float4 s_a[256];
+  __shared__ float4 s_b[256];
+  __shared__ float s_n[256];
+  const int t = threadIdx.x;
+  if (gridDim.y > 1) {
+    const int sg = blockIdx.y;
+    n = sg ? n - seg_split : seg_split;
+    part += sg * part_seg_stride;
+    const int os = sg * fin.out_seg_stride;
     if (MODE == 0) {
-      chan_merge(cnt, a, b, s_n[q * c4 + t], va, vb);
+      fin.save_mean += os;
+      fin.save_invstd += os;
+      if (fin.save_unbiased) fin.save_unbiased += os;
     } else {
-      a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
-      b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+      fin.out_a += os;
+      fin.out_b += os;
     }
   }
-  if (MODE == 0) {
-    const float4 var = make_float4(b.x / cnt, b.y / cnt, b.z / cnt, b.w / cnt);
-    reinterpret_cast<float4*>(fin.save_mean)[t] = a;
-    reinterpret_cast<float4*>(fin.save_invstd)[t] = make_float4(1.0f / sqrtf(var.x + fin.eps), 1.0f / sqrtf(var.y + fin.eps),
-                                                                  1.0f / sqrtf(var.z + fin.eps), 1.0f / sqrtf(var.w + fin.eps));
-    const float ub = cnt > 1.f ? cnt / (cnt - 1.f) : 1.f;
-    const float4 unb = make_float4(var.x * ub, var.y * ub, var.z * ub, var.w * ub);
-    if (fin.save_unbiased) reinterpret_cast<float4*>(fin.save_unbiased)[t] = unb;
-    if (fin.running_mean) {
-      float4 rm = reinterpret_cast<float4*>(fin.running_mean)[t], rv = reinterpret_cast<float4*>(fin.running_var)[t];
-      const float mo = fin.momentum, om = 1.f - fin.momentum;
-      rm = make_float4(om * rm.x + mo * a.x, om * rm.y + mo * a.y, om * rm.z + mo * a.z, om * rm.w + mo * a.w);
-      rv = make_float4(om * rv.x + mo * unb.x, om * rv.y + mo * unb.y, om * rv.z + mo * unb.z, om * rv.w + mo * unb.w);
-      reinterpret_cast<float4*>(fin.running_mean)[t] = rm;
-      reinterpret_cast<float4*>(fin.running_var)[t] = rv;
-    }
-  } else {
-    reinterpret_cast<float4*>(fin.out_a)[t] = a;
-    reinterpret_cast<float4*>(fin.out_b)[t] = b;
-    if (fin.acc_a) {
-      float4 ga = reinterpret_cast<float4*>(fin.acc_a)[t], gb = reinterpret_cast<float4*>(fin.acc_b)[t];
-      reinterpret_cast<float4*>(fin.acc_a)[t] = make_float4(ga.x + a.x, ga.y + a.y, ga.z + a.z, ga.w + a.w);
-      reinterpret_cast<float4*>(fin.acc_b)[t] = make_float4(gb.x + b.x, gb.y + b.y, gb.z + b.z, gb.w + b.w);
-    }
-  }
+  const int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
+  float4 a, b;
+  float cnt;
+  colreduce_merge<MODE>(part, nblocks, n, rows_per_block, c4, rp, t, s_a, s_b, s_n, a, b, cnt);
+  if (t < c4) colreduce_write<MODE>(fin, t, a, b, cnt);
 }
 
 // One 64-lane wave per channel: lanes stride over the per-block partials, then the (n, mean, M2)
@@ -511,7 +567,15 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a
   *reinterpret_cast<float4*>(out + r * out_ld + sub * 4) = o;
 }
 
-static bool fuse_final_enabled() { return true; }  // (the separate final kernels serve more than 256 row blocks only)
+// PCMI_BN_FUSED_FINAL=1: the statistics launch merges its own partials (last-arriving workgroup) instead of leaving
+// them to colreduce_final_kernel -- the round-1..3 form, kept for the A/B (see colreduce_final_kernel)
+static bool fuse_final_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PCMI_BN_FUSED_FINAL");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
 
 static int check_rows(const char* who, const void* p, int64_t ld, int c) {
   PCMI_REQUIRE(p && c > 0 && c % 4 == 0 && c <= 1024 && ld % 4 == 0 && ld >= c && (uintptr_t)p % 16 == 0, PCMI_ERR_INVALID,
@@ -563,22 +627,26 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  const bool fuse = g.nblocks <= kFuseFinalBlocks && fuse_final_enabled();
+  const bool small = g.nblocks <= kFuseFinalBlocks, fuse = small && fuse_final_enabled();
+  fin.eps = eps;
+  fin.momentum = momentum;
+  fin.running_mean = running_mean;
+  fin.running_var = running_var;
+  fin.save_mean = save_mean;
+  fin.save_invstd = save_invstd;
+  fin.save_unbiased = save_unbiased;
   if (fuse) {  // statistics + their final merge in ONE launch (last-arriving workgroup), then the apply pass
     fin.counter = stream_counters(st, 1);
     if (!fin.counter) return PCMI_ERR_HIP;
-    fin.eps = eps;
-    fin.momentum = momentum;
-    fin.running_mean = running_mean;
-    fin.running_var = running_var;
-    fin.save_mean = save_mean;
-    fin.save_invstd = save_invstd;
-    fin.save_unbiased = save_unbiased;
   }
   colreduce_partial_kernel<0><<<g.nblocks, 256, 0, st>>>(x, x_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, n, g.c4, g.rp,
                                                         g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
-  if (!fuse) {
+  if (small && !fuse) {
+    colreduce_final_kernel<0><<<1, 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, 0, 0);
+    PCMI_LAUNCH_CHECK();
+  }
+  if (!small) {
     bn_stats_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, n, c, g.rows_per_block, eps, momentum,
                                                                          running_mean, running_var, save_mean, save_invstd,
                                                                          save_unbiased);
@@ -613,17 +681,28 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  fin.counter = stream_counters(st, 2);
-  if (!fin.counter) return PCMI_ERR_HIP;
+  const bool fuse = fuse_final_enabled();
+  if (fuse) {
+    fin.counter = stream_counters(st, 2);
+    if (!fin.counter) return PCMI_ERR_HIP;
+  }
   fin.eps = eps;
   fin.save_mean = save_mean;
   fin.save_invstd = save_invstd;
   fin.save_unbiased = save_unbiased;
   fin.out_seg_stride = stat_stride;
+  const int64_t part_seg = (int64_t)g.nblocks * 2 * c;
+#if defined(PCMI_BN_DIAG_SKIP_SMALL_STATS)  // timing diagnostic (wrong results): as if the producer had left the partials behind
+  if (longest >= PCMI_BN_DIAG_SKIP_SMALL_STATS)
+#endif
   colreduce_partial_kernel<0><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, nullptr, 0, nullptr, 0, nullptr, nullptr, n,
                                                                            g.c4, g.rp, g.rows_per_block, part, fin, split, 0,
-                                                                           (int64_t)g.nblocks * 2 * c);
+                                                                           part_seg);
   PCMI_LAUNCH_CHECK();
+  if (!fuse) {
+    colreduce_final_kernel<0><<<dim3(1, 2), 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, split, part_seg);
+    PCMI_LAUNCH_CHECK();
+  }
   bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
                                                         res_ld, relu, y, y_ld, split, stat_stride / 4);
   PCMI_LAUNCH_CHECK();
@@ -656,15 +735,26 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  fin.counter = stream_counters(st, 2);
-  if (!fin.counter) return PCMI_ERR_HIP;
+  const bool fuse = fuse_final_enabled();
+  if (fuse) {
+    fin.counter = stream_counters(st, 2);
+    if (!fin.counter) return PCMI_ERR_HIP;
+  }
   fin.out_a = sums;      // dbeta of a segment
   fin.out_b = sums + c;  // dgamma
   fin.out_seg_stride = 2 * c;
+  const int64_t part_seg = (int64_t)g.nblocks * 2 * c;
+#if defined(PCMI_BN_DIAG_SKIP_SMALL_STATS_BWD)
+  if (longest >= PCMI_BN_DIAG_SKIP_SMALL_STATS_BWD)
+#endif
   colreduce_partial_kernel<1><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
                                                                            save_invstd, n, g.c4, g.rp, g.rows_per_block, part,
-                                                                           fin, split, stat_stride, (int64_t)g.nblocks * 2 * c);
+                                                                           fin, split, stat_stride, part_seg);
   PCMI_LAUNCH_CHECK();
+  if (!fuse) {
+    colreduce_final_kernel<1><<<dim3(1, 2), 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, split, part_seg);
+    PCMI_LAUNCH_CHECK();
+  }
   bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
                                                             save_invstd, sums, sums + c, dx, dx_ld, dres, dres_ld,
                                                             dres_accumulate, split, stat_stride / 4, 2 * c / 4, acc_dbeta,
@@ -736,19 +826,23 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  const bool fuse = g.nblocks <= kFuseFinalBlocks && fuse_final_enabled();
+  const bool small = g.nblocks <= kFuseFinalBlocks, fuse = small && fuse_final_enabled();
+  fin.out_a = dbeta;
+  fin.out_b = dgamma;
+  fin.acc_a = acc_dbeta;
+  fin.acc_b = acc_dgamma;
   if (fuse) {
     fin.counter = stream_counters(st, 1);
     if (!fin.counter) return PCMI_ERR_HIP;
-    fin.out_a = dbeta;
-    fin.out_b = dgamma;
-    fin.acc_a = acc_dbeta;
-    fin.acc_b = acc_dgamma;
   }
   colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
                                                         g.c4, g.rp, g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
-  if (!fuse) {
+  if (small && !fuse) {
+    colreduce_final_kernel<1><<<1, 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, 0, 0);
+    PCMI_LAUNCH_CHECK();
+  }
+  if (!small) {
     colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
     PCMI_LAUNCH_CHECK();
   }
