@@ -397,14 +397,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
   PCMI_X3_MFMA(G, am, bh);  \
   PCMI_X3_MFMA(G, ah, bm);  \
   PCMI_X3_MFMA(G, ah, bh)
-#if defined(PCMI_X3_BACK_TO_BACK)
-        // A/B build: the six products of a row group back to back on ONE accumulator (the matrix pipe forwards an
-        // accumulator to the next MFMA only when nothing is issued in between), then the other group's
-        if (g0 && g1) {
-          PCMI_X3_SIX(0);
-          PCMI_X3_SIX(1);
-        } else
-#endif
         if (g0 && g1) {
           PCMI_X3_SIX(0);
           PCMI_X3_SIX(1);
