@@ -304,13 +304,17 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
   if (t < c4) colreduce_write<MODE>(fin, t, a, b, cnt);
 }
 
-// The merge of a statistics launch's partials as a launch of its own: one workgroup per segment, the same fold in the
-// same order as the fused form.  Default since round 4: handing the partials to the last-arriving workgroup INSIDE the
-// statistics launch (release, device-scope atomic, acquire, reloads that miss) cost the step 1.48 ms over its 129
-// BatchNorm statistics launches -- 11.5 us each, more than a kernel boundary and this 3 us kernel
-// (profiles/r04p_bn_statistics_hand_over.txt).
+// The merge of a statistics launch's partials as a launch of its own.  Default since round 4: handing the partials to the
+// last-arriving workgroup INSIDE the statistics launch (release, device-scope atomic, acquire, reloads that miss) cost
+// the step 1.48 ms over its 129 BatchNorm statistics launches -- 11.5 us each, more than a kernel boundary and this
+// kernel (profiles/r04p_bn_statistics_hand_over.txt).
+// A workgroup owns kFinalCols float4 columns of one segment; its 256 / kFinalCols row lanes fold the blocks
+// rl, rl + lanes, ... with every load of a batch in flight (the partials come from other XCDs: each batch is a round
+// trip to memory -- the one-workgroup form of this kernel, 26 blocks per thread in batches of 4, was 7 us of the same
+// latency over and over), then the column threads fold the lanes through LDS.  Fixed order -> deterministic.
+constexpr int kFinalCols = 16, kFinalLanes = 256 / kFinalCols, kFinalBatch = 8;
 template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, int64_t n, int c4, int rp,
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, int64_t n, int c4,
                                                               int rows_per_block, RedFinal fin, int64_t seg_split,
                                                               int64_t part_seg_stride) {
   __shared__ float4 s_a[256];
@@ -332,10 +336,49 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
     }
   }
   const int nblocks = (int)((n + rows_per_block - 1) / rows_per_block);
-  float4 a, b;
-  float cnt;
-  colreduce_merge<MODE>(part, nblocks, n, rows_per_block, c4, rp, t, s_a, s_b, s_n, a, b, cnt);
-  if (t < c4) colreduce_write<MODE>(fin, t, a, b, cnt);
+  const int c = c4 * 4;
+  const int cl = t % kFinalCols, rl = t / kFinalCols;
+  const int col = blockIdx.x * kFinalCols + cl;
+  const bool live = col < c4;
+  float cnt = 0.f;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;  // MODE 0: running (mean, M2); MODE 1: (sum a, sum b)
+  for (int q0 = rl; q0 < nblocks; q0 += kFinalLanes * kFinalBatch) {
+    float4 pa[kFinalBatch], pb[kFinalBatch];
+#pragma unroll
+    for (int u = 0; u < kFinalBatch; ++u) {
+      const int q = q0 + u * kFinalLanes;
+      const bool ok = live && q < nblocks;
+      pa[u] = ok ? *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[u] = ok ? *reinterpret_cast<const float4*>(part + (int64_t)q * 2 * c + c + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kFinalBatch; ++u) {
+      const int q = q0 + u * kFinalLanes;
+      if (q >= nblocks) break;
+      if (MODE == 0) {
+        const int64_t b0 = (int64_t)q * rows_per_block;
+        chan_merge(cnt, a, b, (float)(min(b0 + (int64_t)rows_per_block, n) - b0), pa[u], pb[u]);
+      } else {
+        a.x += pa[u].x; a.y += pa[u].y; a.z += pa[u].z; a.w += pa[u].w;
+        b.x += pb[u].x; b.y += pb[u].y; b.z += pb[u].z; b.w += pb[u].w;
+      }
+    }
+  }
+  s_a[t] = a;
+  s_b[t] = b;
+  s_n[t] = cnt;
+  __syncthreads();
+  if (rl != 0 || !live) return;
+  for (int q = 1; q < kFinalLanes; ++q) {
+    const float4 va = s_a[q * kFinalCols + cl], vb = s_b[q * kFinalCols + cl];
+    if (MODE == 0) {
+      chan_merge(cnt, a, b, s_n[q * kFinalCols + cl], va, vb);
+    } else {
+      a.x += va.x; a.y += va.y; a.z += va.z; a.w += va.w;
+      b.x += vb.x; b.y += vb.y; b.z += vb.z; b.w += vb.w;
+    }
+  }
+  colreduce_write<MODE>(fin, col, a, b, cnt);
 }
 
 // One 64-lane wave per channel: lanes stride over the per-block partials, then the (n, mean, M2)
@@ -643,7 +686,7 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
                                                         g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
   if (small && !fuse) {
-    colreduce_final_kernel<0><<<1, 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, 0, 0);
+    colreduce_final_kernel<0><<<(unsigned)ceil_div(g.c4, kFinalCols), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, 0, 0);
     PCMI_LAUNCH_CHECK();
   }
   if (!small) {
@@ -700,7 +743,8 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
                                                                            part_seg);
   PCMI_LAUNCH_CHECK();
   if (!fuse) {
-    colreduce_final_kernel<0><<<dim3(1, 2), 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, split, part_seg);
+    colreduce_final_kernel<0><<<dim3((unsigned)ceil_div(g.c4, kFinalCols), 2), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, split,
+                                                                                              part_seg);
     PCMI_LAUNCH_CHECK();
   }
   bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
@@ -752,7 +796,8 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
                                                                            fin, split, stat_stride, part_seg);
   PCMI_LAUNCH_CHECK();
   if (!fuse) {
-    colreduce_final_kernel<1><<<dim3(1, 2), 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, split, part_seg);
+    colreduce_final_kernel<1><<<dim3((unsigned)ceil_div(g.c4, kFinalCols), 2), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, split,
+                                                                                              part_seg);
     PCMI_LAUNCH_CHECK();
   }
   bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
@@ -839,7 +884,7 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
                                                         g.c4, g.rp, g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
   if (small && !fuse) {
-    colreduce_final_kernel<1><<<1, 256, 0, st>>>(part, n, g.c4, g.rp, g.rows_per_block, fin, 0, 0);
+    colreduce_final_kernel<1><<<(unsigned)ceil_div(g.c4, kFinalCols), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, 0, 0);
     PCMI_LAUNCH_CHECK();
   }
   if (!small) {
