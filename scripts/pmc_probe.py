@@ -46,6 +46,20 @@ def conv(cin, cout, kmap, K, n_in, n_out, modes="fbw", tag=""):
          2 * M * cin * cout))
 
 
+if os.environ.get("PMC_PROBE_SET") == "gathers":
+  # the three HBM-priced entries of bench.py's kernels[] that sit under 0.40 of the HBM peak:
+  # how many bytes do they actually move?  (forward only; REP launches each, distinct kernel names)
+  ck = cm.stride(key, 2)
+  m2 = cm.kernel_map(key, ck, 2, 2, 0)
+  conv(32, 32, m2, 8, m2.n_in, m2.n_out, modes="f", tag="gather 2^3/s2 ")
+  m1 = cm.kernel_map(ck, ck, 3, 1, 3)
+  n2 = cm.size(ck)
+  x = torch.randn(n2, 32, device=dev)  # (the level-2 3^3 launch shares its kernel with the one above: told apart by launch order)
+  conv(32, 32, m1, 27, n2, n2, modes="f", tag="level2 3^3 ")
+  conv(3, 32, cm.kernel_map(key, key, 3, 1, 0), 27, N, N, modes="f", tag="stem ")
+  torch.cuda.synchronize()
+  print("done")
+  sys.exit(0)
 conv(96, 96, m, 27, N, N)
 # the stride-2 level (~40k rows): its weight gradients take the tile-stationary split-precision kernel (wgrad_x3t_kernel)
 ck = cm.stride(key, 2)
