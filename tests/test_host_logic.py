@@ -462,3 +462,32 @@ def test_flat_sgd_first_step_flag_survives_a_checkpoint(built_lib):
   o._fresh = False
   o.load_state_dict(sd_zero)
   assert o._fresh
+
+
+def test_hardest_draws_consume_the_global_generator_in_the_reference_order():
+  """HardestContrastiveLossTrainer._draw_hardest (run in a helper thread during the forward pass) = the three
+  np.random.choice calls of pc/lib/ddp_trainer.py:198-206 in their order: candidates of cloud 0, of cloud 1, positives;
+  no draw for the positives when there are no more than num_pos of them; injected draws consume nothing."""
+  import numpy as np
+  from pointcontrast_amd.lib.ddp_trainer import HardestContrastiveLossTrainer as T
+  N0, N1, P, num_pos, num_hn = 5000, 4800, 9000, 1024, 256
+  np.random.seed(7)
+  sel0, sel1, pos = T._draw_hardest(N0, N1, P, num_pos, num_hn, None)
+  after = np.random.rand()
+  np.random.seed(7)
+  r0 = np.random.choice(N0, min(N0, num_hn), replace=False)
+  r1 = np.random.choice(N1, min(N1, num_hn), replace=False)
+  rp = np.random.choice(P, num_pos, replace=False)
+  assert np.array_equal(sel0, r0) and np.array_equal(sel1, r1) and np.array_equal(pos, rp) and after == np.random.rand()
+  np.random.seed(7)
+  s0, s1, none = T._draw_hardest(N0, N1, 1000, num_pos, num_hn, None)  # P <= num_pos: every pair is used, nothing drawn
+  assert none is None and np.array_equal(s0, r0) and np.array_equal(s1, r1)
+  np.random.seed(7)
+  inj = dict(sel0=np.arange(3), sel1=np.arange(4), pos_sel=np.arange(5))
+  got = T._draw_hardest(N0, N1, P, num_pos, num_hn, inj)
+  assert all(np.array_equal(a, b) for a, b in zip(got, (inj["sel0"], inj["sel1"], inj["pos_sel"])))
+  np.random.seed(7)
+  first = np.random.rand()
+  np.random.seed(7)
+  T._draw_hardest(N0, N1, P, num_pos, num_hn, inj)
+  assert np.random.rand() == first, "injected draws must not touch the global generator"
