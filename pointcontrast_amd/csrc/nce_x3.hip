@@ -16,8 +16,11 @@
 // A workgroup owns 128 rows (32 per wave, resident as B fragments) and walks a share of the other operand in chunks of
 // 32 rows staged once per workgroup through a two-deep LDS ring (one barrier per chunk).  gridDim.y workgroups share a
 // row tile; the last of them to arrive (common.h: arrive_last) merges their partials in split order: the log-sum-exp
-// states and the loss in the forward, the gradient tiles in the backward -- no finishing launches, no float atomics.
-// Forward + backward at n = 4096, c = 32: 3 launches (pack, forward; pack, backward is 2 more) instead of 8.
+// states, lse and the loss in the forward (two hand-overs: the splits of a tile, then the tiles), the gradient tiles of dq
+// and dk in the backward -- no finishing launches, no float atomics.  Forward + backward: 4 launches (pack + forward,
+// pack + backward) instead of 8, 88 instead of 168 us at n = 4096, c = 32; what is left is hand-over latency, not matrix
+// work (profiles/r04n_loss_block_nce_matrix_cores_and_hardest_host.txt: chunk loops 11.5 / 27 us, finish 14 / 19 us).
+// -DPCMI_NCE_DIAG_NO_LOOP / -DPCMI_NCE_DIAG_NO_FINISH compile one of the two out (timing only, wrong results).
 #include <algorithm>
 #include <cstdlib>
 
