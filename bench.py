@@ -538,7 +538,7 @@ def main():
       del trainer, it, loader
       torch.cuda.empty_cache()
       out["extra"] = {}
-      for key, kw in (("hardest", dict(loss="hardest", voxel=0.025, steps=10, warmup=3)),
+      for key, kw in (("hardest", dict(loss="hardest", voxel=0.025, steps=20, warmup=6)),
                       ("voxel_1cm", dict(loss="nce", voxel=0.01, steps=6, warmup=3))):
         log("extra leg: %s" % key)
         try:
