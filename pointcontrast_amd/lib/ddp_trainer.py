@@ -426,7 +426,6 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
     now; the three np.random.choice calls -- the longest host-side item of this trainer's iteration -- run in a helper
     thread (numpy's shuffle releases the GIL) while this thread enqueues the forward pass, and are joined in front of
     the loss.  Nothing else touches np.random in between, so the global generator is consumed in the reference's order."""
-    import threading
     from ..runtime import handle_pool
     slot = getattr(self, "_slot", 0)
     self._slot = slot ^ 1  # two sets of staging buffers: a prefetched batch must not overwrite the live one
