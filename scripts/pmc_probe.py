@@ -26,7 +26,21 @@ m = cm.kernel_map(key, key, 3, 1, 3)
 N = st.F.shape[0]
 
 
+SEG = [0]
+_mk = torch.zeros(64, 4, device=dev)
+
+
+def segment(label):
+  """Marks the start of a probe segment with a tiny eltwise launch (one workgroup): scripts/pmc_summary.py cuts the
+  dispatch sequence at these markers, so that launches of the SAME kernel on different shapes (wgrad_x3p_kernel<3,3,4>
+  at level 1 and at level 2 -- same name, same grid) are separate rows instead of one averaged row."""
+  check(lib.pcmi_add(ptr(_mk), 4, ptr(_mk), 4, 64, 4, ptr(_mk), 4, cur_stream(dev)))
+  print("SEG %d %s" % (SEG[0], label))
+  SEG[0] += 1
+
+
 def conv(cin, cout, kmap, K, n_in, n_out, modes="fbw", tag=""):
+  segment("%s%d->%d K=%d rows=%d modes=%s" % (tag, cin, cout, K, n_out, modes))
   W = torch.randn((K, cin, cout), device=dev) * 0.05
   x, g = torch.randn(n_in, cin, device=dev), torch.randn(n_out, cout, device=dev)
   yy, gin, gw = torch.empty(n_out, cout, device=dev), torch.empty(n_in, cin, device=dev), torch.empty_like(W)
@@ -65,7 +79,8 @@ conv(96, 96, m, 27, N, N)
 ck = cm.stride(key, 2)
 m1 = cm.kernel_map(ck, ck, 3, 1, 3)
 print("LEVEL2 rows=%d pairs=%d" % (cm.size(ck), m1.M))
-conv(96, 96, m1, 27, cm.size(ck), cm.size(ck), modes="w", tag="level2:")  # (only the gradient: fwd / bwd share kernel names with level 1)
+conv(96, 96, m1, 27, cm.size(ck), cm.size(ck), tag="level2:")  # (its own segment: the kernels share their names with level 1)
+conv(128, 96, m, 27, N, N, tag="in128:")  # the other level-1 shape of the decoder (block8.0.conv1)
 if os.environ.get("PMC_PROBE_ONLY") != "96":
   conv(32, 32, m, 27, N, N)
 torch.cuda.synchronize()
