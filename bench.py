@@ -40,21 +40,42 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 
 
+BATCH_KEYS = ["sinput0_C", "sinput0_F", "sinput1_C", "sinput1_F", "correspondences"]
+
+
+def _batch_path(seed, batch_size, voxel_size):
+  cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pcmi_bench_cache")
+  os.makedirs(cache, exist_ok=True)
+  return os.path.join(cache, "s%d_b%d_v%g.npz" % (seed, batch_size, voxel_size))
+
+
+def generate_batch(seed, batch_size, voxel_size):
+  """Generates the seeded synthetic batch into the local cache (numpy only: safe in a spawned helper process)."""
+  path = _batch_path(seed, batch_size, voxel_size)
+  if not os.path.exists(path):
+    from pointcontrast_amd.lib import synthetic
+    d = synthetic.make_batch(seed=seed, batch_size=batch_size, voxel_size=voxel_size)
+    tmp = path + ".tmp%d.npz" % os.getpid()
+    np.savez(tmp, **{k: d[k] for k in BATCH_KEYS})
+    os.replace(tmp, path)
+  return path
+
+
 def get_batch(seed, batch_size, voxel_size):
   """Seeded synthetic batch in the reference's collate format, cached on local disk."""
   import torch
-  from pointcontrast_amd.lib import synthetic
-  cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pcmi_bench_cache")
-  os.makedirs(cache, exist_ok=True)
-  path = os.path.join(cache, "s%d_b%d_v%g.npz" % (seed, batch_size, voxel_size))
-  keys = ["sinput0_C", "sinput0_F", "sinput1_C", "sinput1_F", "correspondences"]
-  if os.path.exists(path):
-    z = np.load(path)
-    d = {k: z[k] for k in keys}
-  else:
-    d = synthetic.make_batch(seed=seed, batch_size=batch_size, voxel_size=voxel_size)
-    np.savez(path, **{k: d[k] for k in keys})
-  return {k: torch.from_numpy(np.ascontiguousarray(d[k])) for k in keys}
+  z = np.load(generate_batch(seed, batch_size, voxel_size))
+  return {k: torch.from_numpy(np.ascontiguousarray(z[k])) for k in BATCH_KEYS}
+
+
+def get_batches(seeds, batch_size, voxel_size):
+  """Several seeds: the missing ones are generated side by side in spawned helper processes (~10 s of numpy each)."""
+  missing = [sd for sd in seeds if not os.path.exists(_batch_path(sd, batch_size, voxel_size))]
+  if len(missing) > 1:
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(len(missing), 4)) as pool:
+      pool.starmap(generate_batch, [(sd, batch_size, voxel_size) for sd in missing])
+  return [get_batch(sd, batch_size, voxel_size) for sd in seeds]
 
 
 def level1_tensor(batch, device, joint=True):
@@ -304,7 +325,7 @@ def log(msg):
   print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def timed_leg(loss, voxel, batch_size, steps, warmup, model="Res16UNet34C", overrides=()):
+def timed_leg(loss, voxel, batch_size, steps, warmup, model="Res16UNet34C", overrides=(), seeds=(0,)):
   """One more workload on THIS GPU in the same process (N = 1 only): the full training iteration of `loss` at `voxel`,
   `warmup` untimed + `steps` timed iterations bracketed by synchronisations.  Used for the extra.* legs of the JSON line
   (BASELINE configs[2] = HardestContrastive, configs[4] shape = 1 cm voxels), so that the driver's own run witnesses
@@ -316,8 +337,9 @@ def timed_leg(loss, voxel, batch_size, steps, warmup, model="Res16UNet34C", over
   from pointcontrast_amd.lib.timer import AverageMeter, Timer
   cfg = get_config(["net.model=%s" % model, "misc.nceT=0.4", "misc.npos=4096", "opt.lr=0.1", "misc.num_gpus=1",
                     "trainer.batch_size=%d" % batch_size] + list(overrides))
-  batch = get_batch(seed=0, batch_size=batch_size, voxel_size=voxel)
-  loader = FixedBatchLoader([batch], batch_size=batch_size)
+  batches = get_batches(list(seeds), batch_size, voxel)
+  batch = batches[0]
+  loader = FixedBatchLoader(batches, batch_size=batch_size)  # replayed in turn: step i takes batch i mod len(seeds)
   torch.manual_seed(0)
   np.random.seed(0)
   cls = ddp_trainer.PointNCELossTrainer if loss == "nce" else ddp_trainer.HardestContrastiveLossTrainer
@@ -334,9 +356,52 @@ def timed_leg(loss, voxel, batch_size, steps, warmup, model="Res16UNet34C", over
   out = {"value": round(batch_size * steps / dt, 3), "unit": "scene-pairs/sec", "ms_per_step": round(dt / steps * 1e3, 3),
          "steps": steps, "warmup": warmup, "final_loss": round(float(res["loss"]), 5),
          "voxels_per_forward_pair": [int(batch["sinput0_C"].shape[0]), int(batch["sinput1_C"].shape[0])]}
+  if len(batches) > 1:
+    out["batches"] = [{"seed": int(sd), "voxels": [int(b["sinput0_C"].shape[0]), int(b["sinput1_C"].shape[0])],
+                       "correspondences": int(b["correspondences"].shape[0])} for sd, b in zip(seeds, batches)]
   del trainer
   torch.cuda.empty_cache()
   return out
+
+
+def in_step_times(trainer, it, timers, ops, sets=6):
+  """What the level-1 96 -> 96 convolution launches cost INSIDE the training step (HIP events the executor records
+  around them on the streams they run on: pcmi_net_time_ops), over `sets` further iterations with nothing synchronised
+  in between.  In the step the weights are packed once per pass (x3_pack_many_kernel), so a forward / backward-data
+  'launch' here is the main kernel + its fix-up pass; the weight-gradient launch is the kernel + its slab sum."""
+  import torch
+  eng = trainer.engine
+  eng.time_ops(ops, n_sets=sets)
+  for _ in range(sets):
+    trainer._train_iter(it, timers)
+  torch.cuda.synchronize()
+  recs = eng.timed_ms(sets)
+  eng.time_ops([])
+  mean = lambda xs: round(sum(xs) / len(xs), 4) if xs else None
+  pick = lambda kind: [t for r in recs for t in r[kind] if t >= 0]
+  return {"fwd_ms": mean(pick(0)), "bwd_data_ms": mean(pick(1)), "wgrad_ms": mean(pick(2)), "ops_timed": len(ops), "iterations": sets}
+
+
+def fp32_instruction_leg(args, steps=10, warmup=5, limit_s=240):
+  """The same iteration with every split-precision kernel switched off (PCMI_CONV16_X3=0 PCMI_WGRAD_X3T=0 PCMI_NCE_X3=0:
+  the fp32 MFMA instruction throughout -- literally the reference's arithmetic), in a child process of this run."""
+  import subprocess
+  env = dict(os.environ, PCMI_CONV16_X3="0", PCMI_WGRAD_X3T="0", PCMI_NCE_X3="0")
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    env.pop(k, None)
+  cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(args.batch),
+         "--voxel", str(args.voxel), "--loss", args.loss, "--model", args.model, "--no-cpu-baseline", "--no-roofline", "--no-extra"]
+  for a in args.set:
+    cmd += ["--set", a]
+  try:
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=limit_s)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    d = json.loads(line[-1])
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+            "final_loss": d["config"]["final_loss"], "conv_arithmetic": d["config"]["conv_arithmetic"],
+            "switches": "PCMI_CONV16_X3=0 PCMI_WGRAD_X3T=0 PCMI_NCE_X3=0"}
+  except Exception as e:
+    return {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def main():
@@ -465,6 +530,8 @@ def main():
                    "collective": ({"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                                    "allreduce_mb_per_step": round(trainer.flat.numel * 4 / 2 ** 20, 1),
                                    "buckets": len(trainer.reducer.buckets),
+                                   "bucket_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in trainer.reducer.buckets],
+                                   "rccl_max_channels": du.rccl_channel_cap(),
                                    "overlap": trainer.reducer.overlap_report(skip_steps=args.warmup)}
                                   if (world > 1 or forced) else None)},
     }
@@ -475,6 +542,17 @@ def main():
           f.write("\t".join(str(v) for v in r) + "\n")
     log("timed region done: %.2f ms/step" % (elapsed / args.steps * 1e3))
     if not args.no_roofline:
+      instep = None
+      if trainer.engine is not None:
+        ops96 = [i for i, o in enumerate(trainer.engine._ops)
+                 if o["type"] == 0 and o.get("cin") == 96 and o.get("cout") == 96 and o.get("kernel_size") == 3
+                 and o.get("stride") == 1 and trainer.engine._tensors[o["out"]]["level"] == 0]
+        if ops96:
+          try:
+            instep = in_step_times(trainer, it, timers, ops96)
+          except Exception as e:  # measurement garnish: never lose the headline to it
+            instep = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+          log("in-step kernel times: %s" % instep)
       dom, kernels = kernel_rooflines(batch, device, joint=bool(cfg.misc.get("joint_pair", True)) and args.engine == "native")
       log("rooflines done")
       # Which kernel is "the dominant one": launches per step of a shape (from the lowered program) x its stand-alone
@@ -524,11 +602,27 @@ def main():
         return None
 
       def roofline_of(ent):
-        return {"bound": ent["bound"], "achieved": ent["achieved"], "peak": ent["peak"], "unit": ent["unit"],
-                "frac": ent["frac"], "traffic": traffic_of(ent), "traffic_unit": "bytes/launch (PMC, calibrated)",
-                "traffic_note": traffic_note, "kernel": ent["kernel"], "ms": ent["ms"],
-                "launches_per_step": (2 if ent is dom else 1) * n96, "est_step_share_ms": round(share[id(ent)], 3),
-                **{k: ent[k] for k in ("arithmetic", "peak_fp32_mfma", "frac_of_fp32_mfma_peak") if k in ent}}
+        r = {"bound": ent["bound"], "achieved": ent["achieved"], "peak": ent["peak"], "unit": ent["unit"],
+             "frac": ent["frac"], "traffic": traffic_of(ent), "traffic_unit": "bytes/launch (PMC, calibrated)",
+             "traffic_note": traffic_note, "kernel": ent["kernel"], "ms": ent["ms"],
+             "launches_per_step": (2 if ent is dom else 1) * n96, "est_step_share_ms": round(share[id(ent)], 3),
+             **{k: ent[k] for k in ("arithmetic", "peak_fp32_mfma", "frac_of_fp32_mfma_peak") if k in ent}}
+        # the same launches INSIDE the step (events around them on their own streams, next to the other streams' work)
+        if instep and "error" not in instep:
+          if ent is dom:
+            both = [t for t in (instep["fwd_ms"], instep["bwd_data_ms"]) if t]
+            ms_in = sum(both) / len(both) if both else None
+            r["in_step"] = {"fwd_ms": instep["fwd_ms"], "bwd_data_ms": instep["bwd_data_ms"]}
+          else:
+            ms_in = instep["wgrad_ms"]
+          if ms_in:
+            r["in_step_ms"] = round(ms_in, 4)
+            r["in_step_frac"] = round(ent["gflop"] * 1e-3 / (ms_in * 1e-3) / ent["peak"], 4)
+            r["in_step_note"] = ("mean over %d iterations x %d layers, HIP events on the launch stream inside pcmi_net_forward / "
+                                 "_backward; weights pre-packed once per pass" % (instep["iterations"], instep["ops_timed"]))
+        elif instep:
+          r["in_step_error"] = instep["error"]
+        return r
 
       out["roofline"] = roofline_of(first)
       out["roofline_other"] = roofline_of(second)
@@ -538,16 +632,26 @@ def main():
       del trainer, it, loader
       torch.cuda.empty_cache()
       out["extra"] = {}
-      for key, kw in (("hardest", dict(loss="hardest", voxel=0.025, steps=20, warmup=6)),
+      labels = {"hardest": "BASELINE configs[2]: HardestContrastive, 2.5 cm",
+                "voxel_1cm": "BASELINE configs[4] shape: PointInfoNCE, 1 cm voxels, on 1 GPU",
+                "rotating_batches": "BASELINE configs[1] on FOUR different batches (seeds 0-3) replayed in turn: every step sees "
+                                    "other level sizes than the one before (arena / pinned-buffer growth, weight-pack size classes "
+                                    "inside the timed region), as a real loader's batches do (pc/lib/ddp_trainer.py:389)"}
+      for key, kw in (("rotating_batches", dict(loss="nce", voxel=0.025, steps=args.steps, warmup=8, seeds=(0, 1, 2, 3))),
+                      ("hardest", dict(loss="hardest", voxel=0.025, steps=20, warmup=6)),
                       ("voxel_1cm", dict(loss="nce", voxel=0.01, steps=6, warmup=3))):
         log("extra leg: %s" % key)
         try:
           leg = timed_leg(batch_size=args.batch, model=args.model, overrides=list(args.set), **kw)
-          leg["workload"] = ("BASELINE configs[2]: HardestContrastive, 2.5 cm" if key == "hardest"
-                             else "BASELINE configs[4] shape: PointInfoNCE, 1 cm voxels, on 1 GPU")
+          leg["workload"] = labels[key]
+          if key == "rotating_batches":
+            leg["vs_headline"] = round(leg["value"] / out["value"], 4)
           out["extra"][key] = leg
         except Exception as e:  # the headline number must not be lost to a failing extra leg
           out["extra"][key] = {"value": None, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+      log("extra leg: fp32_mfma")
+      out["extra"]["fp32_mfma"] = fp32_instruction_leg(args)
+      out["extra"]["fp32_mfma"]["workload"] = "BASELINE configs[1] on the fp32 MFMA instruction throughout (no split-precision kernel)"
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = run_cpu_baseline_bounded()
     print(json.dumps(out), flush=True)

@@ -412,6 +412,15 @@ int pcmi_net_apply_running_stats(pcmi_net_t* net, int pass, pcmi_stream_t stream
 int pcmi_net_export_tensor(pcmi_net_t* net, int pass, int tensor, int64_t* rows, int* channels, float* out,
                            int64_t out_ld, pcmi_stream_t stream);
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes);
+/* Measurement (bench.py roofline.in_step_ms; the reference has no counterpart: torch.autograd.profiler would be its
+ * tool): timing events around the convolution launches of the ops `ops[0..n_ops)` (indices into the program) INSIDE the
+ * passes -- forward, the backward-data launch and (on the executor's weight-gradient stream) the weight-gradient launch
+ * of the same op -- in a ring of n_sets event sets, one per forward pass enqueued after this call (networks run as one
+ * pass per iteration; the backward pass records into the set of the forward before it).  n_ops == 0 stops timing.
+ * Synchronises the device.  pcmi_net_timed_ms waits for set `set` and returns the elapsed stream time per op in ms
+ * (-1: not recorded). */
+int pcmi_net_time_ops(pcmi_net_t* net, const int* ops, int n_ops, int n_sets);
+int pcmi_net_timed_ms(pcmi_net_t* net, int set, float* fwd_ms, float* bwd_ms, float* wgrad_ms, int n_ops);
 
 #ifdef __cplusplus
 }

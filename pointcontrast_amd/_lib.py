@@ -136,6 +136,8 @@ PROTOTYPES = {
     "pcmi_net_stream_wait_bucket": (C.c_int, [c_vp, c_vp]),
     "pcmi_net_export_tensor": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(c_i64), C.POINTER(C.c_int), c_vp, c_i64, c_vp]),
     "pcmi_net_memory_bytes": (C.c_int, [c_vp, C.POINTER(c_sz)]),
+    "pcmi_net_time_ops": (C.c_int, [c_vp, C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "pcmi_net_timed_ms": (C.c_int, [c_vp, C.c_int, C.POINTER(c_f32), C.POINTER(c_f32), C.POINTER(c_f32), C.c_int]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -148,23 +148,51 @@ struct pcmi_net {
   std::vector<pcmi::PassState> passes;
   // side: the weight gradients of a backward pass (off the critical path: nothing downstream reads them) at the lowest
   // stream priority, with a workspace of their own
-  hipStream_t side[1] = {nullptr};
-  hipEvent_t ev_main[1] = {nullptr}, ev_side[1] = {nullptr};
+  // side[1] (PCMI_WGRAD_SIDE2=1, an experiment): the SMALL weight-gradient launches (levels under 8192 rows, strided and
+  // 1x1 layers: ~45 latency-bound launches per step that use a few dozen compute units each) on a stream of their own, so
+  // that they run beside the large level-1 launches instead of queueing behind them
+  static constexpr int kSides = 2;
+  hipStream_t side[kSides] = {nullptr, nullptr};
+  hipEvent_t ev_main[kSides] = {nullptr, nullptr}, ev_side[kSides] = {nullptr, nullptr};
   // what produced the gradient bucket the running `ready` callback is about: the chain up to the bucket's last op on
   // the backward stream, and the weight gradients enqueued so far on the side stream (pcmi_net_stream_wait_bucket)
-  hipEvent_t ev_bkt_main = nullptr, ev_bkt_side = nullptr;
-  bool bkt_valid = false, bkt_side = false;
-  pcmi::DevBuf ws_side[1];
+  hipEvent_t ev_bkt_main = nullptr, ev_bkt_side[kSides] = {nullptr, nullptr};
+  bool bkt_valid = false, bkt_side[kSides] = {false, false};
+  pcmi::DevBuf ws_side[kSides];
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
+  // pcmi_net_time_ops: timing events around the convolution launches of selected ops INSIDE the passes (bench.py:
+  // roofline.in_step_ms -- what the dominant kernel costs where it runs, next to the other streams, not stand-alone)
+  // A ring of `timed_sets` event sets, one per forward pass enqueued since (its backward uses the same set): the
+  // caller runs that many iterations WITHOUT synchronising and reads the sets afterwards.
+  static constexpr int kTimedEv = 6;
+  std::vector<int> timed_ops;
+  std::vector<hipEvent_t> timed_ev;  // [set][timed op][forward begin / end, backward-data begin / end, weight-gradient begin / end (side stream)]
+  std::vector<char> timed_hit;       // [set][timed op]: bit 0 forward, bit 1 backward-data, bit 2 weight gradient recorded
+  int timed_sets = 0, timed_cur = -1;
+  int timed_slot(int op) const {     // index into timed_hit (x kTimedEv: into timed_ev) of `op` in the current set, or -1
+    if (timed_ops.empty() || timed_cur < 0) return -1;
+    for (size_t q = 0; q < timed_ops.size(); ++q)
+      if (timed_ops[q] == op) return (timed_cur % timed_sets) * (int)timed_ops.size() + (int)q;
+    return -1;
+  }
+  void timed_clear() {
+    for (hipEvent_t e : timed_ev) (void)hipEventDestroy(e);
+    timed_ev.clear();
+    timed_ops.clear();
+    timed_hit.clear();
+    timed_sets = 0;
+    timed_cur = -1;
+  }
   ~pcmi_net() {
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < 1; ++i) {
+    timed_clear();
+    for (int i = 0; i < kSides; ++i) {
       if (side[i]) (void)hipStreamDestroy(side[i]);
       if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
       if (ev_side[i]) (void)hipEventDestroy(ev_side[i]);
+      if (ev_bkt_side[i]) (void)hipEventDestroy(ev_bkt_side[i]);
     }
     if (ev_bkt_main) (void)hipEventDestroy(ev_bkt_main);
-    if (ev_bkt_side) (void)hipEventDestroy(ev_bkt_side);
   }
 };
 
@@ -278,7 +306,7 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
       const int hs = ps.x3_jobs_slot;
       ps.x3_jobs_slot ^= 1;
       const size_t need = jobs.size() * sizeof(X3PackJob);
-      if (!ps.x3_jobs_copied[hs]) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_jobs_copied[hs], hipEventDisableTiming));
+      if (!ps.x3_jobs_copied[hs]) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_jobs_copied[hs], hipEventDisableTiming | hipEventBlockingSync));
       PCMI_HIP_CHECK(hipEventSynchronize(ps.x3_jobs_copied[hs]));  // the copy that last read this host buffer (two tables ago)
       if (need > ps.x3_jobs_host_cap[hs]) {
         if (ps.x3_jobs_host[hs]) PCMI_HIP_CHECK(hipHostFree(ps.x3_jobs_host[hs]));
@@ -337,6 +365,20 @@ struct BackwardJob {
   hipStream_t st = nullptr;
 };
 
+// Test hooks of the bucket hand-over (tests/test_gpu_bucket_sync.py; read per call, never set in production):
+//   PCMI_DEBUG_SIDE_DELAY_US=<n>        the weight-gradient stream starts every backward pass n microseconds late (a spin
+//                                       kernel at its head), so that it trails the chain by far more than it ever does
+//   PCMI_DEBUG_SKIP_BUCKET_SIDE_WAIT=1  pcmi_net_stream_wait_bucket leaves out the wait for the weight-gradient stream --
+//                                       the negative control: with the delay above a consumer must then see stale gradients
+__global__ void debug_delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();  // constant-rate counter (100 MHz)
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static long debug_env_long(const char* name) {
+  const char* e = getenv(name);
+  return e ? atol(e) : 0;
+}
+
 static int ensure_streams(pcmi_net& n) {
   if (n.side[0]) return PCMI_OK;
   // the weight gradients are off the critical path: lowest priority, so that the chain's kernels are dispatched
@@ -347,13 +389,13 @@ static int ensure_streams(pcmi_net& n) {
   // (a stream confined to a subset of the compute units -- hipExtStreamCreateWithCUMask, so that the chain's small
   //  kernels always find free units -- was tried: such a stream cannot be non-blocking and serialises against the
   //  caller's default stream, 165 against 253 pairs/s with any mask; profiles/r03j_bench_ab_cu_mask.txt)
-  for (int i = 0; i < 1; ++i) {
+  for (int i = 0; i < pcmi_net::kSides; ++i) {
     PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, least));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
+    PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_side[i], hipEventDisableTiming));
   }
   PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_main, hipEventDisableTiming));
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_side, hipEventDisableTiming));
   return PCMI_OK;
 }
 
@@ -368,11 +410,13 @@ struct BackwardRun {
   pcmi_ready_fn ready;
   void* ready_ctx;
   // set by begin()
-  hipStream_t st = nullptr, wst = nullptr;
+  hipStream_t st = nullptr, wst = nullptr;  // wst: the side stream of the op being differentiated (step)
+  bool two_sides = false;
+  int64_t small_rows = 0;
   PassState* ps = nullptr;
   DevBuf* wws = nullptr;
+  bool pending[pcmi_net::kSides] = {false, false}, used[pcmi_net::kSides] = {false, false};
   float* scratch_g = nullptr;
-  bool side_pending = false, side_used = false;
   std::vector<int> bucket_last;
 
   BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
@@ -380,10 +424,12 @@ struct BackwardRun {
       : n(net), job(j), params(prm), grads(g), bucket_lo_host(blo), n_buckets(nb), ready(r), ready_ctx(rc) {}
 
   int join_side() {  // `st` continues only after the weight gradients enqueued so far
-    if (!side_pending) return PCMI_OK;
-    PCMI_HIP_CHECK(hipEventRecord(n.ev_side[0], wst));
-    PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));
-    side_pending = false;
+    for (int q = 0; q < pcmi_net::kSides; ++q) {
+      if (!pending[q]) continue;
+      PCMI_HIP_CHECK(hipEventRecord(n.ev_side[q], n.side[q]));
+      PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[q], 0));
+      pending[q] = false;
+    }
     return PCMI_OK;
   }
   int bucket_of(int64_t offp) const {
@@ -414,11 +460,19 @@ struct BackwardRun {
     scratch_g = (float*)ps->small.p;
     rc = ensure_streams(n);
     if (rc) return rc;
-    rc = n.ws_side[0].reserve(ps->ws.cap, n.side[0]);
-    if (rc) return rc;
+    two_sides = debug_env_long("PCMI_WGRAD_SIDE2") != 0;
+    small_rows = 8192;  // (= the default of PCMI_WGRAD_X3T: what is under it takes the pair-list kernel)
+    for (int q = 0; q < (two_sides ? 2 : 1); ++q) {
+      rc = n.ws_side[q].reserve(ps->ws.cap, n.side[q]);
+      if (rc) return rc;
+      pending[q] = used[q] = false;
+    }
     wst = n.side[0];
     wws = &n.ws_side[0];
-    side_pending = side_used = false;
+    if (const long us = debug_env_long("PCMI_DEBUG_SIDE_DELAY_US"); us > 0) {
+      debug_delay_kernel<<<1, 1, 0, wst>>>((long long)us * 100);
+      PCMI_LAUNCH_CHECK();
+    }
     n.bkt_valid = false;
     // bucket -> first op (lowest index) that owns parameters of it: the bucket is final after that op
     bucket_last.assign(n_buckets, -1);
@@ -446,16 +500,32 @@ struct BackwardRun {
       // (weight gradients of the largest layers ON the chain instead of the side stream -- they cannot share a CU with the
       //  chain's kernels anyway, two of their workgroups fill register file and LDS -- were measured: 16.47 against 15.85 ms
       //  per step with the 175k-row layers in the chain, 17.1 with everything from 8000 rows: profiles/r04i_*)
-      PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
-      PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[0], 0));
-      side_pending = side_used = true;
+      const int sq = (two_sides && (std::min(n_in, n_out) < small_rows || op.kernel_size != 3 || op.stride != 1 ||
+                                    std::min(op.cin, op.cout) < 64)) ? 1 : 0;
+      wst = n.side[sq];
+      wws = &n.ws_side[sq];
+      PCMI_HIP_CHECK(hipEventRecord(n.ev_main[sq], st));
+      PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sq], 0));
+      pending[sq] = used[sq] = true;
+      const int tw = n.timed_slot(i);
+      if (tw >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tw + 4], wst));
       rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose, grads + op.w_off,
                                   op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
       if (rc) return rc;
+      if (tw >= 0) {
+        PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tw + 5], wst));
+        n.timed_hit[tw] |= 4;
+      }
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
+        const int tq = n.timed_slot(i);
+        if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 2], st));
         rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
                                   n_in, pl.acc_in, ps->ws.p, ps->ws.cap, st);
+        if (tq >= 0 && !rc) {
+          PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 3], st));
+          n.timed_hit[tq] |= 2;
+        }
       }
     } else if (op.type == PCMI_OP_BN) {
       const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
@@ -486,8 +556,10 @@ struct BackwardRun {
     for (int b = 0; b < n_buckets; ++b)
       if (bucket_last[b] == i && ready) {
         PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_main, st));
-        if (side_used) PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_side, wst));
-        n.bkt_side = side_used;
+        for (int q = 0; q < pcmi_net::kSides; ++q) {
+          if (used[q]) PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_side[q], n.side[q]));
+          n.bkt_side[q] = used[q];
+        }
         n.bkt_valid = true;
         ready(ready_ctx, b);
       }
@@ -617,7 +689,7 @@ int pcmi_net_export_tensor(pcmi_net_t* net, int pass, int tensor, int64_t* rows,
 
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes) {
   PCMI_REQUIRE(net && bytes, PCMI_ERR_INVALID, "net_memory_bytes: null argument");
-  size_t b = net->ws_side[0].cap;
+  size_t b = net->ws_side[0].cap + net->ws_side[1].cap;
   for (auto& p : net->passes) b += p.act.cap + p.ws.cap + p.grad.cap + p.small.cap + p.x3_packs.cap + p.x3_jobs_dev.cap;
   *bytes = b;
   return PCMI_OK;
@@ -721,7 +793,11 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       PCMI_HIP_CHECK(hipMalloc((void**)&ps.upd_dev, sizeof(BnRunningUpdate) * n_bn));
       ps.upd_cap = n_bn;
     }
-    if (!ps.upd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.upd_copied, hipEventDisableTiming));
+    // This wait is also what keeps the enqueueing thread ONE pass ahead of the GPU (the event sits behind the previous
+    // forward of this pass).  hipEventBlockingSync: the thread sleeps in the driver instead of spinning on the event --
+    // round 4's bench line had forward == forward_cpu == 8.9 ms of a 15.2 ms step, i.e. a core per rank burnt in this
+    // wait (with 8 ranks x (enqueue + draw + RCCL proxy threads) that is 8 cores spinning next to the loader workers).
+    if (!ps.upd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.upd_copied, hipEventDisableTiming | hipEventBlockingSync));
     PCMI_HIP_CHECK(hipEventSynchronize(ps.upd_copied));  // the previous table has left the pinned buffer
   }
   ps.in_feats = in_feats;
@@ -736,14 +812,25 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   if (rc) return rc;
   g_prof_fwd.lap(2);
   // ---- run --------------------------------------------------------------------------------------
+  if (!n.timed_ops.empty()) {  // the next event set of the ring (pcmi_net_time_ops); its old records are dropped
+    ++n.timed_cur;
+    const size_t per = n.timed_ops.size(), base = (size_t)(n.timed_cur % n.timed_sets) * per;
+    for (size_t q = 0; q < per; ++q) n.timed_hit[base + q] = 0;
+  }
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
     const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
     if (op.type == PCMI_OP_CONV) {
+      const int tq = n.timed_slot(i);
+      if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 0], st));
       rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
                           op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, ps.ws.p, ps.ws.cap,
                           st);
+      if (tq >= 0 && !rc) {
+        PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 1], st));
+        n.timed_hit[tq] |= 1;
+      }
     } else if (op.type == PCMI_OP_BN) {
       View r = {nullptr, 0};
       if (op.in2 >= 0) r = act_view(n, ps, op.in2);
@@ -796,7 +883,48 @@ int pcmi_net_stream_wait_bucket(pcmi_net_t* net, pcmi_stream_t stream) {
   PCMI_REQUIRE(net, PCMI_ERR_INVALID, "net_stream_wait_bucket: null argument");
   PCMI_REQUIRE(net->bkt_valid, PCMI_ERR_INVALID, "net_stream_wait_bucket: only valid inside a pcmi_ready_fn callback");
   PCMI_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), net->ev_bkt_main, 0));
-  if (net->bkt_side) PCMI_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), net->ev_bkt_side, 0));
+  if (!debug_env_long("PCMI_DEBUG_SKIP_BUCKET_SIDE_WAIT"))
+    for (int q = 0; q < pcmi_net::kSides; ++q)
+      if (net->bkt_side[q]) PCMI_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), net->ev_bkt_side[q], 0));
+  return PCMI_OK;
+}
+
+int pcmi_net_time_ops(pcmi_net_t* net, const int* ops, int n_ops, int n_sets) {
+  PCMI_REQUIRE(net && (n_ops == 0 || (ops && n_sets > 0)) && n_ops >= 0 && n_ops <= 64 && n_sets <= 64, PCMI_ERR_INVALID,
+               "net_time_ops: bad argument");
+  PCMI_HIP_CHECK(hipDeviceSynchronize());  // nothing in flight records into the events that go away
+  net->timed_clear();
+  if (n_ops == 0) return PCMI_OK;
+  for (int q = 0; q < n_ops; ++q)
+    PCMI_REQUIRE(ops[q] >= 0 && ops[q] < (int)net->ops.size() && net->ops[ops[q]].type == PCMI_OP_CONV, PCMI_ERR_INVALID,
+                 "net_time_ops: op %d is not a convolution of this network", ops[q]);
+  net->timed_ops.assign(ops, ops + n_ops);
+  net->timed_sets = n_sets;
+  net->timed_hit.assign((size_t)n_sets * n_ops, 0);
+  for (int e = 0; e < pcmi_net::kTimedEv * n_sets * n_ops; ++e) {
+    hipEvent_t ev = nullptr;
+    PCMI_HIP_CHECK(hipEventCreate(&ev));
+    net->timed_ev.push_back(ev);
+  }
+  return PCMI_OK;
+}
+
+int pcmi_net_timed_ms(pcmi_net_t* net, int set, float* fwd_ms, float* bwd_ms, float* wgrad_ms, int n_ops) {
+  PCMI_REQUIRE(net && fwd_ms && bwd_ms && wgrad_ms && n_ops == (int)net->timed_ops.size() && set >= 0 && set < net->timed_sets,
+               PCMI_ERR_INVALID, "net_timed_ms: set %d / %d slots asked, %d sets of %d ops are timed", set, n_ops,
+               net ? net->timed_sets : 0, net ? (int)net->timed_ops.size() : 0);
+  constexpr int E = pcmi_net::kTimedEv;
+  for (int q = 0; q < n_ops; ++q) {
+    const size_t h = (size_t)set * n_ops + q;
+    float* dst[3] = {&fwd_ms[q], &bwd_ms[q], &wgrad_ms[q]};
+    for (int kind = 0; kind < 3; ++kind) {
+      *dst[kind] = -1.f;  // not recorded in this set (or no backward-data: the op reads the network input)
+      if (net->timed_hit[h] & (1 << kind)) {
+        PCMI_HIP_CHECK(hipEventSynchronize(net->timed_ev[E * h + 2 * kind + 1]));
+        PCMI_HIP_CHECK(hipEventElapsedTime(dst[kind], net->timed_ev[E * h + 2 * kind], net->timed_ev[E * h + 2 * kind + 1]));
+      }
+    }
+  }
   return PCMI_OK;
 }
 

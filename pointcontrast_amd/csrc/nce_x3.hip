@@ -339,6 +339,11 @@ __device__ __forceinline__ void nce_bwd_body(const u32x4* __restrict__ own_rows,
 #pragma unroll
       for (int term = 0; term < 3; ++term) bk[ct][term] = s_st[buf][384 + (term * 2 + ct) * 64 + lane];
     const bool diag = b0 == a_base;  // (wave-uniform) the chunk holding this wave's own rows
+    // (wave-uniform) the chunk reaches past row n: its padding rows b >= n have zero operands, so s = 0 and
+    // p = exp2(-lse) -- with lse below about -88 (unnormalised features, a tiny T) that is inf, the three-term split of
+    // inf has NaN terms, and NaN x the zero column fragments of the padding rows is NaN in the gradient of REAL rows.
+    // The forward masks these rows with kFloor; here their weight is forced to zero.
+    const bool edge = b0 + kChunk > n;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       v4f w0, w1;
@@ -349,6 +354,7 @@ __device__ __forceinline__ void nce_bwd_body(const u32x4* __restrict__ own_rows,
           const float p = __builtin_amdgcn_exp2f(fmaf(sacc[g][tt][r], c1, -(FOR_K ? lb[tt][r] : lo[g])));
           float w = p * gs;
           if (diag && 16 * tt + 4 * kk + r == 16 * g + i) w = (p - 1.f) * gs;
+          if (edge && b0 + 16 * tt + 4 * kk + r >= n) w = 0.f;
           if (tt == 0) w0[r] = w; else w1[r] = w;
         }
       u32x4 wt[3];

@@ -304,6 +304,91 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
   if (t < c4) colreduce_write<MODE>(fin, t, a, b, cnt);
 }
 
+// The backward sums of colreduce_partial_kernel<1> within 48 registers and 4 KiB of LDS, for large activations.
+// Why: one wgrad_x3p_kernel<3,3,4> workgroup per compute unit leaves 52 VGPRs per lane and 12 KiB of LDS
+// (scripts/kernel_resources.py); the backward statistics of the level-1 BatchNorms run entirely beside such a launch and
+// the 102-register kernel above was confined to the 32 compute units it leaves free -- 114-121 us for 200 MB where the
+// same pass takes 69 us next to the smaller weight-gradient instantiation (profiles/r04zy_*).
+// How: a thread owns TWO channels instead of four (half the accumulators / statistics in registers) and keeps four
+// rows in flight through raw buffer loads with 32-bit byte offsets (one offset register per operand; a row past the
+// block's end is an out-of-range offset that reads zeros and adds nothing).  Same partial layout [block][2][c] and the
+// same blocks as the kernel above, so colreduce_final_kernel<1> merges either; the order in which a block's rows are
+// added differs (256 / (c / 2) row lanes), fixed and deterministic all the same.
+template <bool MASKED>
+__global__ __launch_bounds__(256, 10) void bn_bwd_stats_lean_kernel(
+    const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld,
+    const float* __restrict__ ymask, int64_t y_ld, const float* __restrict__ mean, const float* __restrict__ invstd,
+    int64_t n, int c, int rows_per_block, float* __restrict__ part, int64_t seg_split, int in_seg_stride,
+    int64_t part_seg_stride) {
+  __shared__ float2 s_a[256];
+  __shared__ float2 s_b[256];
+  typedef float lf2 __attribute__((ext_vector_type(2)));
+  constexpr uint32_t kOut = 0x80000000u;
+  constexpr int kFlags = 0x00020000;
+  const int t = threadIdx.x;
+  const int c2 = c >> 1, rp = 256 / c2;
+  const int col = t % c2, rl = t / c2;
+  int64_t base = 0;
+  if (gridDim.y > 1) {  // two segments, as colreduce_partial_kernel
+    const int sg = blockIdx.y;
+    base = sg ? seg_split : 0;
+    n = sg ? n - seg_split : seg_split;
+    part += sg * part_seg_stride;
+    mean += sg * in_seg_stride;
+    invstd += sg * in_seg_stride;
+    if ((int64_t)blockIdx.x * rows_per_block >= n) return;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const uint32_t first = (uint32_t)(base + r0) + (uint32_t)rl, last = (uint32_t)(base + min(r0 + (int64_t)rows_per_block, n));
+  lf2 a = {0.f, 0.f}, b = {0.f, 0.f};
+  if (rl < rp) {
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7FFFFFFF, kFlags);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, 0x7FFFFFFF, kFlags);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MASKED ? ymask : x), 0, 0x7FFFFFFF, kFlags);
+    const uint32_t xs = (uint32_t)x_ld * 4u, gs = (uint32_t)dy_ld * 4u, ys = (uint32_t)y_ld * 4u, cb = (uint32_t)col * 8u;
+    const lf2 mu = *reinterpret_cast<const lf2*>(mean + 2 * col), is = *reinterpret_cast<const lf2*>(invstd + 2 * col);
+    constexpr int kRows = 4;
+#pragma unroll 1
+    for (uint32_t r = first; r < last; r += (uint32_t)(kRows * rp)) {
+      lf2 xv[kRows], gv[kRows], yv[kRows];
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        const uint32_t ru = r + (uint32_t)(u * rp);
+        const bool ok = ru < last;
+        xv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(xr, ok ? ru * xs + cb : kOut, 0, 0));
+        gv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(gr, ok ? ru * gs + cb : kOut, 0, 0));
+        if constexpr (MASKED) yv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(yr, ok ? ru * ys + cb : kOut, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) {
+        lf2 g = gv[u];
+        if constexpr (MASKED) {
+          g[0] = yv[u][0] > 0.f ? g[0] : 0.f;
+          g[1] = yv[u][1] > 0.f ? g[1] : 0.f;
+        }
+        a[0] += g[0];
+        a[1] += g[1];
+        b[0] = fmaf(g[0], (xv[u][0] - mu[0]) * is[0], b[0]);
+        b[1] = fmaf(g[1], (xv[u][1] - mu[1]) * is[1], b[1]);
+      }
+    }
+  }
+  s_a[t] = make_float2(a[0], a[1]);
+  s_b[t] = make_float2(b[0], b[1]);
+  __syncthreads();
+  if (t < c2) {
+    float2 sa = s_a[t], sb = s_b[t];
+    for (int q = 1; q < rp; ++q) {
+      const float2 va = s_a[q * c2 + t], vb = s_b[q * c2 + t];
+      sa.x += va.x; sa.y += va.y;
+      sb.x += vb.x; sb.y += vb.y;
+    }
+    float* p0 = part + (int64_t)blockIdx.x * 2 * c;
+    reinterpret_cast<float2*>(p0)[t] = sa;
+    reinterpret_cast<float2*>(p0 + c)[t] = sb;
+  }
+}
+
 // The merge of a statistics launch's partials as a launch of its own.  Default since round 4: handing the partials to the
 // last-arriving workgroup INSIDE the statistics launch (release, device-scope atomic, acquire, reloads that miss) cost
 // the step 1.48 ms over its 129 BatchNorm statistics launches -- 11.5 us each, more than a kernel boundary and this
@@ -612,6 +697,20 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a
 
 // PCMI_BN_FUSED_FINAL=1: the statistics launch merges its own partials (last-arriving workgroup) instead of leaving
 // them to colreduce_final_kernel -- the round-1..3 form, kept for the A/B (see colreduce_final_kernel)
+// PCMI_BN_LEAN_ROWS: from this many rows the backward statistics take the 48-register form of colreduce_partial_kernel
+// (0 = never).  Read per call (A/B in one process).  Same sums in the same order: the row lanes and blocks are
+// unchanged, only how many of a thread's rows are in flight at once.
+static int64_t bn_lean_rows() {
+  const char* e = getenv("PCMI_BN_LEAN_ROWS");
+  return e ? (int64_t)atoll(e) : (int64_t)65536;
+}
+
+static bool bn_lean_eligible(int64_t n, int c, int64_t x_ld, int64_t dy_ld, int64_t y_ld) {
+  const int64_t lean = bn_lean_rows();
+  const int64_t ld = std::max(std::max(x_ld, dy_ld), y_ld);
+  return lean > 0 && n >= lean && c % 2 == 0 && c / 2 <= 256 && n * ld * 4 <= 0x7FFFFF00ll;  // 32-bit byte offsets
+}
+
 static bool fuse_final_enabled() {
   static const bool on = [] {
     const char* e = getenv("PCMI_BN_FUSED_FINAL");
@@ -779,7 +878,8 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  const bool fuse = fuse_final_enabled();
+  const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
+  const bool fuse = fuse_final_enabled() && !lean;  // (the lean statistics kernel never merges: it has no registers for it)
   if (fuse) {
     fin.counter = stream_counters(st, 2);
     if (!fin.counter) return PCMI_ERR_HIP;
@@ -791,9 +891,18 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
 #if defined(PCMI_BN_DIAG_SKIP_SMALL_STATS_BWD)
   if (longest >= PCMI_BN_DIAG_SKIP_SMALL_STATS_BWD)
 #endif
-  colreduce_partial_kernel<1><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
-                                                                           save_invstd, n, g.c4, g.rp, g.rows_per_block, part,
-                                                                           fin, split, stat_stride, part_seg);
+  if (lean && relu_mask_y)
+    bn_bwd_stats_lean_kernel<true><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
+                                                                                save_invstd, n, c, g.rows_per_block, part, split,
+                                                                                stat_stride, part_seg);
+  else if (lean)
+    bn_bwd_stats_lean_kernel<false><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, nullptr, 0, save_mean, save_invstd,
+                                                                                 n, c, g.rows_per_block, part, split, stat_stride,
+                                                                                 part_seg);
+  else
+    colreduce_partial_kernel<1><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
+                                                                             save_invstd, n, g.c4, g.rp, g.rows_per_block, part,
+                                                                             fin, split, stat_stride, part_seg);
   PCMI_LAUNCH_CHECK();
   if (!fuse) {
     colreduce_final_kernel<1><<<dim3((unsigned)ceil_div(g.c4, kFinalCols), 2), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, split,
@@ -871,7 +980,8 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  const bool small = g.nblocks <= kFuseFinalBlocks, fuse = small && fuse_final_enabled();
+  const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
+  const bool small = g.nblocks <= kFuseFinalBlocks, fuse = small && fuse_final_enabled() && !lean;
   fin.out_a = dbeta;
   fin.out_b = dgamma;
   fin.acc_a = acc_dbeta;
@@ -880,8 +990,15 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
     fin.counter = stream_counters(st, 1);
     if (!fin.counter) return PCMI_ERR_HIP;
   }
-  colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
-                                                        g.c4, g.rp, g.rows_per_block, part, fin);
+  if (lean && relu_mask_y)
+    bn_bwd_stats_lean_kernel<true><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n, c,
+                                                             g.rows_per_block, part, 0, 0, 0);
+  else if (lean)
+    bn_bwd_stats_lean_kernel<false><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, nullptr, 0, save_mean, save_invstd, n, c,
+                                                              g.rows_per_block, part, 0, 0, 0);
+  else
+    colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
+                                                          g.c4, g.rp, g.rows_per_block, part, fin);
   PCMI_LAUNCH_CHECK();
   if (small && !fuse) {
     colreduce_final_kernel<1><<<(unsigned)ceil_div(g.c4, kFinalCols), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, 0, 0);

@@ -266,11 +266,15 @@ class NativeEngine:
     only on the LAST backward of the iteration."""
     assert self._held[pass_id] is not None, "forward(training=True) first"
     d = d_out if (d_out.stride(1) == 1 and d_out.stride(0) % 4 == 0) else d_out.contiguous()
-    cb, lo_arr, nb = self._ready_args(reducer, self._wait_bucket)
+    errors = []
+    cb, lo_arr, nb = self._ready_args(reducer, self._wait_bucket, errors)
     with torch.cuda.device(d.device):
-      check(lib.pcmi_net_backward(self._h, pass_id, ptr(d), d.stride(0), ptr(self.flat.w), ptr(self.flat.g), lo_arr, nb, cb,
-                                  None, cur_stream(d.device)))
+      rc = lib.pcmi_net_backward(self._h, pass_id, ptr(d), d.stride(0), ptr(self.flat.w), ptr(self.flat.g), lo_arr, nb, cb,
+                                 None, cur_stream(d.device))
     self._held[pass_id] = None
+    if errors:  # raised inside a bucket callback: ctypes would have printed and dropped it (ADVICE round 4)
+      raise errors[0]
+    check(rc)
 
   def _wait_bucket(self, stream):
     """Inside a bucket-ready callback: `stream` (the reducer's communication stream) waits for the chain AND the
@@ -278,17 +282,46 @@ class NativeEngine:
     check(lib.pcmi_net_stream_wait_bucket(self._h, C.c_void_p(stream.cuda_stream)))
 
   @staticmethod
-  def _ready_args(reducer, wait_bucket=None):
+  def _ready_args(reducer, wait_bucket=None, errors=None):
+    """errors: a list that receives what a bucket callback raised.  The callback runs inside a ctypes trampoline, which
+    prints and DROPS a Python exception: the bucket would stay un-reduced on this rank only -- silent divergence between
+    the ranks.  The caller re-raises the first entry once pcmi_net_backward has returned."""
     cb, lo_arr, nb = READY_FN(), None, 0
     if reducer is not None and reducer.active:
       order = sorted(range(len(reducer.buckets)), key=lambda b: reducer.buckets[b][0])
       lo_arr = (C.c_int64 * len(order))(*[reducer.buckets[b][0] for b in order])
       nb = len(order)
-      if wait_bucket is None:  # (tests drive the callback with CPU stand-ins for the executor)
-        cb = READY_FN(lambda _ctx, q: reducer._launch(order[q]))
-      else:
-        cb = READY_FN(lambda _ctx, q: reducer._launch(order[q], order_behind=wait_bucket))
+
+      def ready(_ctx, q):
+        try:
+          if wait_bucket is None:  # (tests drive the callback with CPU stand-ins for the executor)
+            reducer._launch(order[q])
+          else:
+            reducer._launch(order[q], order_behind=wait_bucket)
+        except BaseException as e:  # noqa: B902  (must not escape into the C caller)
+          if errors is None:
+            raise
+          errors.append(e)
+
+      cb = READY_FN(ready)
     return cb, lo_arr, nb
+
+  def time_ops(self, ops, n_sets=8):
+    """Timing events around the convolution launches of program ops `ops` inside the next `n_sets` passes (forward and
+    backward-data); [] stops.  See include/pcmi.h (pcmi_net_time_ops)."""
+    arr = (C.c_int * max(len(ops), 1))(*ops)
+    self._timed = (list(ops), n_sets)
+    check(lib.pcmi_net_time_ops(self._h, arr, len(ops), n_sets))
+
+  def timed_ms(self, n_sets=None):
+    """[(fwd_ms, bwd_data_ms, wgrad_ms) per op] of the first `n_sets` recorded sets (waits for them; -1 = not recorded)."""
+    ops, sets = getattr(self, "_timed", ([], 0))
+    out = []
+    for s_ in range(min(n_sets or sets, sets)):
+      f, b, w = (C.c_float * len(ops))(), (C.c_float * len(ops))(), (C.c_float * len(ops))()
+      check(lib.pcmi_net_timed_ms(self._h, s_, f, b, w, len(ops)))
+      out.append((list(f), list(b), list(w)))
+    return out
 
   def activation(self, pass_id, tensor_id):
     """Copy of activation tensor `tensor_id` of the last forward of pass `pass_id` ([rows, channels], current stream)."""

@@ -64,12 +64,13 @@ class ContrastiveLossTrainer:
 
     Model = load_model(config.net.model)
     model = Model(num_feats, config.net.model_n_out, config, D=3).to(self.cur_device)
-    if self.world_size > 1:  # what DDP's constructor does: rank 0's parameters everywhere
-      for p in model.parameters():
-        torch.distributed.broadcast(p.data, src=0)
     self.model = model
     self.flat = du.FlatParameters(model.parameters())
-    self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", 32.0),
+    if self.world_size > 1:
+      # what DDP's constructor does (pc/lib/ddp_trainer.py:96-102: rank 0's parameters everywhere) -- as ONE collective
+      # over the flat buffer every parameter is a view of, not one per tensor (round 4: 250 small broadcasts)
+      torch.distributed.broadcast(self.flat.w, src=0)
+    self.reducer = du.GradReducer(self.flat, bucket_mb=config.misc.get("bucket_mb", du.DEFAULT_BUCKET_MB),
                                    force=config.misc.get("force_reducer", False),
                                    profile=config.misc.get("reducer_profile", False))
     # misc.engine: "native" = whole forward / backward as one libpcmi call each (engine.py);
@@ -207,6 +208,16 @@ class ContrastiveLossTrainer:
   def _prepare_loss(self, prep, draws):
     pass
 
+  def _join_draws(self):
+    """Waits for a helper thread that is consuming the GLOBAL numpy generator (HardestContrastiveLossTrainer's draws).
+    Called before anything else may touch that generator -- another batch's draws, or next(data_loader_iter) whose
+    dataset transforms use np.random / random in-process (num_workers = 0) -- so that the stream is consumed in the
+    reference's order whatever the prefetch mode.  A failure is re-raised where the draws are used."""
+    th = getattr(self, "_draw_thread", None)
+    if th is not None:
+      th.join()
+      self._draw_thread = None
+
   def _prep_mark(self, phase):
     if not self.config.misc.get("host_profile", False):
       return
@@ -233,6 +244,7 @@ class ContrastiveLossTrainer:
         return nxt, 0.0
       logging.warning("injected draws: the prefetched batch is discarded and a fresh one is prepared")
     data_timer.tic()
+    self._join_draws()
     input_dict = next(data_loader_iter)
     data_time = data_timer.toc(average=False)
     return self._prepare(input_dict, draws), data_time
@@ -254,6 +266,7 @@ class ContrastiveLossTrainer:
       return
     if draws is None and self._prefetch_mode() == "thread":
       self._prefetch_err = None
+      self._join_draws()
       th = threading.Thread(target=self._prefetch_worker, args=(next(data_loader_iter),), daemon=True)
       th.start()
       self._prefetch_thread = th
@@ -305,6 +318,7 @@ class ContrastiveLossTrainer:
     if getattr(self, "_last_iter", False):
       return
     if draws is None and self._prefetch_mode() == "inline":
+      self._join_draws()
       self._prefetched = self._prepare(next(data_loader_iter))
 
   def _forward_pair(self, prep):
@@ -425,7 +439,8 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
     started with the rest of the batch preparation: the key set of the positive pairs is built on the planning stream
     now; the three np.random.choice calls -- the longest host-side item of this trainer's iteration -- run in a helper
     thread (numpy's shuffle releases the GIL) while this thread enqueues the forward pass, and are joined in front of
-    the loss.  Nothing else touches np.random in between, so the global generator is consumed in the reference's order."""
+    the loss -- and in front of anything else that may touch np.random (_join_draws: the next batch's draws, the loader's
+    next item), so the global generator is consumed in the reference's order in every prefetch mode."""
     from ..runtime import handle_pool
     slot = getattr(self, "_slot", 0)
     self._slot = slot ^ 1  # two sets of staging buffers: a prefetched batch must not overwrite the live one
@@ -450,8 +465,10 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
       except BaseException as e:  # re-raised by the joining thread
         box["error"] = e
 
+    self._join_draws()  # (a prefetched batch: the previous batch's draws come first, as in the reference's loop)
     th = threading.Thread(target=work, name="pcmi-hardest-draws", daemon=True)
     th.start()
+    self._draw_thread = th
     prep["hardest"] = dict(thread=th, box=box, keys=keys, n=(N0, N1), pp=pp, slot=slot, plan=plan)
 
   def _finish_prepared_loss(self, h):

@@ -15,6 +15,24 @@ import torch
 import torch.distributed as dist
 
 
+# Gradient buckets (GradReducer): 151.4 MB of Res16UNet34C gradients in THREE all-reduces (64 + 64 + ~23 MB, cut from the
+# end of the flat buffer = the order backward finishes them).  Round 4 used 32 MB = 5 buckets: each all-reduce is a few
+# RCCL kernels that compete with the backward kernels for compute units, and the forced 1-rank path cost 3.5 % of the
+# step; the last bucket -- the one whose all-reduce cannot hide behind backward -- is the SMALL one either way.
+DEFAULT_BUCKET_MB = 64.0
+# RCCL channels = workgroups per collective kernel.  The weight-gradient kernel that runs beside the collectives leaves 32
+# of the 256 compute units free on purpose (csrc/spconv_wgrad_x3.hip); RCCL's default on this part is more channels than
+# that, which then queue behind it.  16 channels keep a 64 MB all-reduce well under a millisecond of a ~10 ms backward.
+# Only a DEFAULT: NCCL_MAX_NCHANNELS in the environment wins, PCMI_RCCL_MAX_CHANNELS=0 leaves RCCL's own choice.
+DEFAULT_RCCL_MAX_CHANNELS = 16
+
+
+def rccl_channel_cap():
+  """The cap init_process_group applied (what bench.py reports in config.collective), or None."""
+  v = os.environ.get("NCCL_MAX_NCHANNELS")
+  return int(v) if v and v.isdigit() else None
+
+
 def get_world_size():
   return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -38,6 +56,9 @@ def init_process_group(proc_rank=None, world_size=None, backend=None):
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1))
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
   os.environ.setdefault("MASTER_PORT", "29500")
+  cap = int(os.environ.get("PCMI_RCCL_MAX_CHANNELS", DEFAULT_RCCL_MAX_CHANNELS))
+  if use_cuda and cap > 0:
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(cap))  # read by RCCL when the communicator is created
   dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
   return rank, world
 
@@ -91,7 +112,7 @@ class FlatParameters:
 class GradReducer:
   """Bucketed all-reduce(SUM) of FlatParameters.g overlapped with backward."""
 
-  def __init__(self, flat, bucket_mb=32.0, process_group=None, force=False, profile=False):
+  def __init__(self, flat, bucket_mb=DEFAULT_BUCKET_MB, process_group=None, force=False, profile=False):
     self.flat, self.pg = flat, process_group
     # profile: per-bucket events (ready on the compute stream, done on the comm stream) + end of backward, so that a
     # scaling run can report how much of the all-reduce was hidden behind backward (overlap_report)
@@ -139,14 +160,16 @@ class GradReducer:
     communication stream waits for the current stream's position, as a DDP bucket hook does."""
     if not self.active or self._launched[b]:
       return
-    self._launched[b] = True
-    self.n_launched_total += 1
     lo, hi, _ = self.buckets[b]
     chunk = self.flat.g[lo:hi]
+    if self.cuda and order_behind is not None:
+      order_behind(self.comm_stream)  # may raise: the bucket is then NOT marked launched and finish() retries it
+    # (marked once nothing before the all-reduce can fail any more: a bucket marked launched whose all-reduce was never
+    #  enqueued would be skipped by finish() -- this rank alone would step on un-reduced gradients; ADVICE round 4)
+    self._launched[b] = True
+    self.n_launched_total += 1
     if self.cuda:
       ev = None
-      if order_behind is not None:
-        order_behind(self.comm_stream)
       if order_behind is None or self.profile:
         ev = torch.cuda.Event(enable_timing=self.profile)
         ev.record(torch.cuda.current_stream(chunk.device))

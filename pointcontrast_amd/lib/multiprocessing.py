@@ -50,6 +50,7 @@ def rank_environment(rank, world_size, port, base=None):
 def run(proc_rank, world_size, port, error_pipe, fun, fun_args, fun_kwargs, init_group=True):
   """Child side: rendezvous environment, process group, the function, teardown; a traceback goes to the parent."""
   from . import distributed as du
+  code = 0
   try:
     os.environ.update(rank_variables(proc_rank, world_size, port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -58,17 +59,30 @@ def run(proc_rank, world_size, port, error_pipe, fun, fun_args, fun_kwargs, init
     fun(*fun_args, **fun_kwargs)
   except KeyboardInterrupt:
     pass  # stopped by the parent
-  except BaseException:
-    try:
-      error_pipe.send(traceback.format_exc())
-    finally:
+  except SystemExit as e:  # sys.exit(n) inside fun: not a failure by itself -- its code is the child's exit code
+    code = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+    if code != 0:
       try:
-        du.destroy_process_group()
-      finally:
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(1)  # not sys.exit: a rank stuck in a collective's helper threads must not keep the process alive
-  else:
+        error_pipe.send("rank %d called sys.exit(%r)" % (proc_rank, e.code))
+      except (OSError, ValueError):
+        pass
+  except BaseException:
+    code = 1
+    try:
+      # (the parent reads the pipe WHILE it waits for the process -- mp_wait on sentinels and pipes -- so a traceback
+      #  larger than the pipe buffer does not block this send for ever)
+      error_pipe.send(traceback.format_exc())
+    except (OSError, ValueError):
+      pass
+  if code != 0:
+    try:
+      du.destroy_process_group()
+    finally:
+      sys.stdout.flush()
+      sys.stderr.flush()
+      error_pipe.close()
+      os._exit(code)  # not sys.exit: a rank stuck in a collective's helper threads must not keep the process alive
+  try:
     du.destroy_process_group()
   finally:
     error_pipe.close()
@@ -100,21 +114,33 @@ def multi_proc_run(num_proc, fun, fun_args=(), fun_kwargs=None, init_group=True)
     procs.append(p)
     pipes.append(rx)
   pending = dict((p.sentinel, i) for i, p in enumerate(procs))
+  by_pipe = dict((rx, i) for i, rx in enumerate(pipes))
+  traces = {}  # rank -> what its pipe delivered (received as soon as it is readable, not after the child has exited)
+  open_pipes = set(pipes)
+
+  def drain(rx):
+    i = by_pipe[rx]
+    try:
+      traces[i] = rx.recv()
+    except (EOFError, OSError):
+      pass  # closed without a message: a clean exit, or a death in native code
+    open_pipes.discard(rx)
+
   try:
     while pending:
-      for s in mp_wait(list(pending)):
+      for s in mp_wait(list(pending) + list(open_pipes)):
+        if s in by_pipe:
+          if s in open_pipes:
+            drain(s)
+          continue
         i = pending.pop(s)
         p = procs[i]
         p.join()
         if p.exitcode != 0:
-          trace = None
-          try:
-            if pipes[i].poll(0.5):
-              trace = pipes[i].recv()
-          except (EOFError, OSError):
-            pass
+          if pipes[i] in open_pipes and pipes[i].poll(0.5):
+            drain(pipes[i])
           _stop(procs)
-          raise ChildException(trace or "rank %d exited with code %s without a Python traceback" % (i, p.exitcode),
+          raise ChildException(traces.get(i) or "rank %d exited with code %s without a Python traceback" % (i, p.exitcode),
                                rank=i, exitcode=p.exitcode)
   except BaseException:
     _stop(procs)

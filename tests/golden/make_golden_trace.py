@@ -1,7 +1,10 @@
-"""Generates tests/golden/golden_trace.npz: an UNSYNCHRONISED 20-iteration loss trace of the PointInfoNCE training step.
+"""Generates tests/golden/golden_trace.npz: an UNSYNCHRONISED 20-iteration loss trace of the PointInfoNCE training step
+-- and, with `hardest`, tests/golden/golden_trace_hardest.npz: the same for HardestContrastiveLossTrainer
+(pc/lib/ddp_trainer.py:186-238,278-326; the candidate / positive draws of :198-206 injected per step).
 
-Run from the repo root (CPU only, ~10 minutes):
+Run from the repo root (CPU only, ~10 minutes each):
     python tests/golden/make_golden_trace.py
+    python tests/golden/make_golden_trace.py hardest
 
 What runs: the oracle's restatement of the reference iteration (pc/lib/ddp_trainer.py:380-440 -- two forwards of
 Res16UNet14, pair selection with injected draws, PointInfoNCE, backward, SGD(lr 0.1, momentum 0.8, wd 1e-4); pinned
@@ -46,6 +49,18 @@ def draws_of(step, nq):
   return d
 
 
+HN_POS, HN_SAMPLES, POS_THRESH, NEG_THRESH = 1024, 256, 0.1, 1.4  # pc/config/defaults.yaml (per batch of 1 pair)
+
+
+def hardest_draws_of(step, N0, N1, P):
+  """The three np.random.choice calls of pc/lib/ddp_trainer.py:198-206 for iteration `step`, from a seeded generator."""
+  rng = np.random.RandomState(2000 + step)
+  sel0 = rng.choice(N0, min(N0, HN_SAMPLES), replace=False)
+  sel1 = rng.choice(N1, min(N1, HN_SAMPLES), replace=False)
+  pos_sel = rng.choice(P, HN_POS, replace=False) if P > HN_POS else None
+  return dict(sel0=sel0, sel1=sel1, pos_sel=pos_sel)
+
+
 def initial_model():
   from oracle import model_ref as mr
   torch.manual_seed(0)
@@ -56,6 +71,38 @@ def initial_model():
 
 def weight_checksum(model):
   return float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+
+
+def main_hardest():
+  from oracle import loss_ref as lr, sparse_ref as sr
+  torch.set_num_threads(min(16, os.cpu_count() or 1))
+  batch = make_batch()
+  pp = batch["correspondences"].numpy()
+  N0, N1 = batch["sinput0_C"].shape[0], batch["sinput1_C"].shape[0]
+  m32 = initial_model()
+  m64 = copy.deepcopy(m32).double()
+  chk = weight_checksum(m32)
+  o32, o64 = lr.make_sgd(m32.parameters(), LR), lr.make_sgd(m64.parameters(), LR)
+  trace = {torch.float32: [], torch.float64: []}
+  for step in range(STEPS):
+    d = hardest_draws_of(step, N0, N1, len(pp))
+    for m, o, dt in ((m32, o32, torch.float32), (m64, o64, torch.float64)):
+      o.zero_grad()
+      F0 = m(sr.SparseTensorRef(batch["sinput0_F"].to(dt), coords=batch["sinput0_C"].numpy())).F
+      F1 = m(sr.SparseTensorRef(batch["sinput1_F"].to(dt), coords=batch["sinput1_C"].numpy())).F
+      pos, neg, _ = lr.hardest_contrastive_loss(F0, F1, pp, d["sel0"], d["sel1"], d["pos_sel"], POS_THRESH, NEG_THRESH)
+      loss = pos + neg
+      loss.backward()
+      o.step()
+      trace[dt].append(float(loss.detach()))
+    print("step %2d  fp32 %.6f  fp64 %.6f  rel %.2e" % (step, trace[torch.float32][-1], trace[torch.float64][-1],
+                                                       abs(trace[torch.float32][-1] - trace[torch.float64][-1]) / abs(trace[torch.float64][-1])),
+          flush=True)
+  out = os.path.join(ROOT, "tests", "golden", "golden_trace_hardest.npz")
+  np.savez_compressed(out, loss32=np.array(trace[torch.float32]), loss64=np.array(trace[torch.float64]),
+                      weight_checksum=np.array(chk), steps=np.array(STEPS), lr=np.array(LR),
+                      **{k: batch[k].numpy() for k in ("sinput0_C", "sinput0_F", "sinput1_C", "sinput1_F", "correspondences")})
+  print("wrote", out)
 
 
 def main():
@@ -91,4 +138,4 @@ def main():
 
 
 if __name__ == "__main__":
-  main()
+  main_hardest() if "hardest" in sys.argv[1:] else main()

@@ -1,0 +1,199 @@
+"""The hand-over of a gradient bucket from the native executor to its consumer.
+
+Since round 4 the backward chain no longer joins the weight-gradient stream at a bucket boundary: the executor records
+both positions as events and the CONSUMER's stream waits for them (pcmi_net_stream_wait_bucket, csrc/engine.hip).  A
+missing or wrong wait cannot change any result in a 1-rank group whose all-reduce is the identity -- so these tests look
+at what the consumer's stream SEES:
+  * a 1-rank RCCL group whose all-reduce is replaced by a copy of the bucket ON the communication stream: the copy must
+    equal the final gradients bit for bit -- also with the weight-gradient stream started 30 ms late
+    (PCMI_DEBUG_SIDE_DELAY_US), and it must NOT with the wait for that stream compiled out of the hand-over
+    (PCMI_DEBUG_SKIP_BUCKET_SIDE_WAIT: the negative control that shows the test can fail);
+  * two ranks on ONE GPU over gloo (RCCL refuses two ranks per device; everything but the transport is the N > 1 path:
+    launcher, flat broadcast, bucket callbacks, communication stream, finish, loss all-reduce): the all-reduced gradients
+    of a step equal the sum of the two ranks' local gradients of the same step computed without a reducer.
+Reference: torch DistributedDataParallel's bucket hooks, pc/lib/ddp_trainer.py:96-102."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch(seed, n_pairs=2):
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.ddp_data_loaders import default_collate_pair_fn
+  rng = np.random.RandomState(seed)
+  return default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.7) for _ in range(n_pairs)])
+
+
+def _draws(batch, step=0):
+  pp = batch["correspondences"].numpy()
+  nq = len(np.unique(pp[:, 0]))
+  d = dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(step)))
+  if nq > 256:
+    d["sampled_inds"] = np.random.RandomState(step).choice(nq, 256, replace=False)
+  return d
+
+
+def _trainer(batch, overrides=(), seed=7):
+  from pointcontrast_amd.lib import ddp_trainer
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader
+  cfg = get_config(["net.model=Res16UNet14", "misc.nceT=0.4", "misc.npos=256", "misc.bucket_mb=4"] + list(overrides))
+  torch.manual_seed(seed)
+  return ddp_trainer.PointNCELossTrainer(cfg, FixedBatchLoader([batch], 2))
+
+
+def _iterate(tr, batch, step=0):
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  return tr._train_iter(iter(FixedBatchLoader([batch], 2)), [AverageMeter(), Timer(), Timer()], draws=_draws(batch, step))
+
+
+def _snapshot_step(monkeypatch, batch, env):
+  """One iteration with every bucket's all-reduce replaced by `snap[bucket] = g[bucket]` on the communication stream.
+  Returns (snapshot, final gradients, buckets)."""
+  from pointcontrast_amd.lib import distributed as du
+  for k in ("PCMI_DEBUG_SIDE_DELAY_US", "PCMI_DEBUG_SKIP_BUCKET_SIDE_WAIT"):
+    monkeypatch.delenv(k, raising=False)
+  for k, v in env.items():
+    monkeypatch.setenv(k, v)  # read per call by the executor (getenv)
+  tr = _trainer(batch, ["misc.force_reducer=True"])
+  assert tr.reducer.active and len(tr.reducer.buckets) >= 3
+  g = tr.flat.g
+  snap = torch.full_like(g, float("nan"))
+  real = du.dist.all_reduce
+  seen = []
+
+  class _Done:
+    def wait(self):
+      pass
+
+  def fake(t, *a, **kw):
+    off = (t.data_ptr() - g.data_ptr()) // 4
+    if t.is_cuda and 0 <= off < g.numel() and t.numel() > 1:  # a gradient bucket (the scalar loss goes to the real one)
+      snap[off:off + t.numel()].copy_(t)  # on torch's current stream = the reducer's communication stream
+      seen.append((off, t.numel(), torch.cuda.current_stream().cuda_stream))
+      return _Done()
+    return real(t, *a, **kw)
+
+  monkeypatch.setattr(du.dist, "all_reduce", fake)
+  _iterate(tr, batch)  # warm-up: arenas, streams, the executor's first-call paths
+  snap.fill_(float("nan"))
+  del seen[:]
+  _iterate(tr, batch, step=1)
+  torch.cuda.synchronize()
+  assert len(seen) == len(tr.reducer.buckets) and all(s[2] == tr.reducer.comm_stream.cuda_stream for s in seen)
+  return snap.clone(), g.clone(), list(tr.reducer.buckets)
+
+
+@pytest.fixture()
+def one_rank_group():
+  from pointcontrast_amd.lib import distributed as du
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  port = s.getsockname()[1]
+  s.close()
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+  du.init_process_group(0, 1)
+  yield
+  du.destroy_process_group()
+  for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    os.environ.pop(k, None)
+
+
+def test_bucket_consumer_sees_the_final_gradients(monkeypatch, one_rank_group):
+  batch = _batch(2)
+  snap, g, _ = _snapshot_step(monkeypatch, batch, {})
+  assert not torch.isnan(snap).any() and torch.equal(snap, g)
+  # the weight-gradient stream 30 ms behind: every bucket is announced long before its weight gradients exist
+  snap, g, _ = _snapshot_step(monkeypatch, batch, {"PCMI_DEBUG_SIDE_DELAY_US": "30000"})
+  assert torch.equal(snap, g), "a bucket was handed to its consumer before the weight-gradient stream had written it"
+
+
+def test_bucket_hand_over_without_the_side_stream_wait_is_caught(monkeypatch, one_rank_group):
+  """Negative control: with the wait for the weight-gradient stream left out of pcmi_net_stream_wait_bucket and that
+  stream delayed, the consumer copies buckets whose convolution weight gradients have not been written yet.  (The step's
+  own result stays right -- the optimiser is behind the pass's one join -- which is exactly why only a look at the
+  consumer's stream can see the bug.)"""
+  batch = _batch(2)
+  snap, g, buckets = _snapshot_step(monkeypatch, batch, {"PCMI_DEBUG_SIDE_DELAY_US": "30000", "PCMI_DEBUG_SKIP_BUCKET_SIDE_WAIT": "1"})
+  stale = [b for b, (lo, hi, _) in enumerate(buckets) if not torch.equal(snap[lo:hi], g[lo:hi])]
+  assert stale, "the delayed weight-gradient stream was not observable: the positive test above proves nothing"
+
+
+# ---- two ranks on one GPU over gloo ---------------------------------------------------------------------------------
+def _two_rank_worker(out_dir):
+  import threading
+  import torch.distributed as dist
+  sys.path.insert(0, ROOT)
+  from pointcontrast_amd.lib import distributed as du
+  rank = int(os.environ["RANK"])
+  du.init_process_group(rank, 2, backend="gloo")  # both ranks on cuda:0 (LOCAL_RANK % device_count)
+  rec = {"rank": rank, "device": torch.cuda.current_device()}
+  box = {}
+
+  def probe():
+    try:
+      t = torch.full((8,), float(rank + 1), device="cuda")
+      dist.all_reduce(t)
+      torch.cuda.synchronize()
+      box["ok"] = bool((t == 3.0).all())
+    except Exception as e:  # this torch build's gloo has no device path
+      box["err"] = "%s: %s" % (type(e).__name__, e)
+
+  th = threading.Thread(target=probe, daemon=True)
+  th.start()
+  th.join(90)
+  if not box.get("ok"):
+    rec["skip"] = box.get("err", "gloo all-reduce of a device tensor did not finish within 90 s")
+    json.dump(rec, open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+    os._exit(0)  # (a helper thread may be stuck inside the collective)
+  batch = _batch(10 + rank)
+  # (different initial weights per rank: only the broadcast of rank 0's makes them equal)
+  tr = _trainer(batch, ["opt.lr=0.0", "opt.momentum=0.0", "opt.weight_decay=0.0", "misc.num_gpus=2", "trainer.batch_size=4"],
+                seed=7 + rank)
+  assert tr.world_size == 2 and tr.reducer.active and len(tr.reducer.buckets) >= 3
+  w0 = tr.flat.w.clone()
+  _iterate(tr, batch)  # warm-up
+  _iterate(tr, batch, step=1)
+  torch.cuda.synchronize()
+  reduced = tr.flat.g.clone()
+  assert torch.equal(tr.flat.w, w0), "lr 0 must leave the weights where the broadcast put them"
+  wsum = tr.flat.w.double().sum().cpu()
+  both = [torch.zeros_like(wsum), torch.zeros_like(wsum)]
+  dist.all_gather(both, wsum)
+  rec["same_weights"] = bool(both[0] == both[1])
+  # the same step without a reducer: this rank's own gradients, everything synchronised
+  tr.reducer.active = False
+  _iterate(tr, batch, step=1)
+  torch.cuda.synchronize()
+  local = tr.flat.g.clone()
+  total = local.cpu()
+  dist.all_reduce(total)  # CPU tensors: a + b, exactly what the device all-reduce of two ranks computes
+  rec["equal"] = bool(torch.equal(reduced.cpu(), total))
+  rec["max_abs_diff"] = float((reduced.cpu() - total).abs().max())
+  rec["differs_from_local"] = bool(not torch.equal(reduced, local))
+  rec["grad_norm"] = float(total.norm())
+  rec["buckets"] = len(tr.reducer.buckets)
+  json.dump(rec, open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
+  du.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_reduce_to_the_sum_of_their_gradients(tmp_path):
+  from pointcontrast_amd.lib import multiprocessing as mpu
+  mpu.multi_proc_run(2, fun=_two_rank_worker, fun_args=(str(tmp_path),), init_group=False)
+  recs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+  if any("skip" in r for r in recs):
+    pytest.skip("gloo cannot all-reduce device tensors in this build: %s" % [r.get("skip") for r in recs])
+  for r in recs:
+    assert r["same_weights"], "the flat-buffer broadcast did not give both ranks rank 0's parameters"
+    assert r["differs_from_local"] and r["grad_norm"] > 0, "the two ranks must contribute different gradients"
+    assert r["equal"], "all-reduced gradients != sum of the ranks' local gradients (max |diff| %.3e)" % r["max_abs_diff"]

@@ -18,6 +18,28 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 
+def _check_trace(dev, G, steps):
+  l32, l64 = G["loss32"], G["loss64"]
+  rel_dev, rel_32 = np.abs(dev - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
+  for s in range(steps):
+    print("step %2d  device %.6f  fp32 oracle %.6f  fp64 oracle %.6f  |dev-64| %.2e  |32-64| %.2e" %
+          (s, dev[s], l32[s], l64[s], rel_dev[s], rel_32[s]))
+  # the first step starts from identical weights: the north_star tolerance applies as is
+  assert rel_dev[0] <= 1e-4, (dev[0], l64[0])
+  # afterwards: inside the envelope of what fp32 arithmetic does to this trace (x4: two different fp32 evaluation orders
+  # are two samples of the same sensitive map), never below the 1e-4 the first step is held to
+  # (the envelope looks two steps ahead: WHEN a trajectory crosses a kink differs by a step or two between two fp32
+  #  evaluation orders of the same map)
+  ahead = np.array([rel_32[:min(s + 3, steps)].max() for s in range(steps)])
+  env = np.maximum(ahead, 1e-4)
+  bad = [(s, float(rel_dev[s]), float(env[s])) for s in range(steps) if rel_dev[s] > 4 * env[s]]
+  assert not bad, "device trace leaves the fp32 envelope around the fp64 trace: %s" % bad[:5]
+  # same descent: the loss falls by the same amount over the 20 steps (mean of the last five vs the first)
+  drop = lambda t: t[0] - t[-5:].mean()
+  assert drop(l64) > 0.2, "the fixture's loss must actually fall (%.3f)" % drop(l64)
+  assert abs(drop(dev) - drop(l64)) <= 0.05 * drop(l64), (drop(dev), drop(l64))
+
+
 def test_twenty_unsynchronised_iterations_follow_the_oracle_trace():
   import make_golden_trace as gt
   from pointcontrast_amd.lib.config import get_config
@@ -41,22 +63,34 @@ def test_twenty_unsynchronised_iterations_follow_the_oracle_trace():
   it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
   losses = [trainer._train_iter(it, timers, draws=gt.draws_of(step, nq))["loss"] for step in range(steps)]
   dev = np.array([float(l) for l in losses])  # one synchronisation, after the last step
-  l32, l64 = G["loss32"], G["loss64"]
-  rel_dev, rel_32 = np.abs(dev - l64) / np.abs(l64), np.abs(l32 - l64) / np.abs(l64)
-  for s in range(steps):
-    print("step %2d  device %.6f  fp32 oracle %.6f  fp64 oracle %.6f  |dev-64| %.2e  |32-64| %.2e" %
-          (s, dev[s], l32[s], l64[s], rel_dev[s], rel_32[s]))
-  # the first step starts from identical weights: the north_star tolerance applies as is
-  assert rel_dev[0] <= 1e-4, (dev[0], l64[0])
-  # afterwards: inside the envelope of what fp32 arithmetic does to this trace (x4: two different fp32 evaluation orders
-  # are two samples of the same sensitive map), never below the 1e-4 the first step is held to
-  # (the envelope looks two steps ahead: WHEN a trajectory crosses a kink differs by a step or two between two fp32
-  #  evaluation orders of the same map)
-  ahead = np.array([rel_32[:min(s + 3, steps)].max() for s in range(steps)])
-  env = np.maximum(ahead, 1e-4)
-  bad = [(s, float(rel_dev[s]), float(env[s])) for s in range(steps) if rel_dev[s] > 4 * env[s]]
-  assert not bad, "device trace leaves the fp32 envelope around the fp64 trace: %s" % bad[:5]
-  # same descent: the loss falls by the same amount over the 20 steps (mean of the last five vs the first)
-  drop = lambda t: t[0] - t[-5:].mean()
-  assert drop(l64) > 0.2, "the fixture's loss must actually fall (%.3f)" % drop(l64)
-  assert abs(drop(dev) - drop(l64)) <= 0.05 * drop(l64), (drop(dev), drop(l64))
+  _check_trace(dev, G, steps)
+
+
+def test_twenty_unsynchronised_hardest_iterations_follow_the_oracle_trace():
+  """The same for HardestContrastiveLossTrainer (pc/lib/ddp_trainer.py:186-238,278-326), whose host side -- the draws in a
+  helper thread, the key set and the index uploads on the planning stream -- was rewritten in round 4: 20 iterations
+  with the candidate / positive draws of every step injected (the fixture's seeds), nothing synchronised in between.
+  The mined negatives are NOT injected: an arg-min that flips between two fp32 evaluation orders is part of what the
+  envelope measures (the fp32 oracle mines with its own features as well)."""
+  import make_golden_trace as gt
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader
+  from pointcontrast_amd.lib.ddp_trainer import HardestContrastiveLossTrainer
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  G = np.load(os.path.join(HERE, "golden", "golden_trace_hardest.npz"))
+  steps = int(G["steps"])
+  batch = {k: torch.from_numpy(G[k]) for k in ("sinput0_C", "sinput0_F", "sinput1_C", "sinput1_F", "correspondences")}
+  cfg = get_config(["net.model=%s" % gt.MODEL, "opt.lr=%g" % float(G["lr"]), "misc.engine=native", "trainer.batch_size=1"])
+  assert (cfg.trainer.num_pos_per_batch, cfg.trainer.num_hn_samples_per_batch, cfg.trainer.pos_thresh, cfg.trainer.neg_thresh) == \
+      (gt.HN_POS, gt.HN_SAMPLES, gt.POS_THRESH, gt.NEG_THRESH)
+  loader = FixedBatchLoader([batch], batch_size=1)
+  trainer = HardestContrastiveLossTrainer(cfg, loader)
+  ref0 = gt.initial_model()
+  assert abs(gt.weight_checksum(ref0) - float(G["weight_checksum"])) <= 1e-9 * float(G["weight_checksum"]), \
+      "this torch build initialises the model differently from the one that wrote the fixture: regenerate it"
+  trainer.model.load_state_dict(ref0.state_dict())
+  N0, N1, P = batch["sinput0_C"].shape[0], batch["sinput1_C"].shape[0], batch["correspondences"].shape[0]
+  it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
+  losses = [trainer._train_iter(it, timers, draws=gt.hardest_draws_of(step, N0, N1, P))["loss"] for step in range(steps)]
+  dev = np.array([float(l) for l in losses])  # one synchronisation, after the last step
+  _check_trace(dev, G, steps)

@@ -40,6 +40,27 @@ def _die_without_traceback(out_dir):
   time.sleep(120)
 
 
+def _huge_traceback(out_dir):
+  import torch.distributed as dist
+  if dist.get_rank() == 1:
+    raise ValueError("x" * (1 << 20))  # 1 MiB of message: far more than a pipe buffer holds
+  time.sleep(120)
+
+
+def _exit_zero(out_dir):
+  import torch.distributed as dist
+  with open(os.path.join(out_dir, "ran%d" % dist.get_rank()), "w") as f:
+    f.write("1")
+  sys.exit(0)
+
+
+def _exit_five(out_dir):
+  import torch.distributed as dist
+  if dist.get_rank() == 0:
+    sys.exit(5)
+  time.sleep(120)
+
+
 def _alive(pid):
   try:
     os.kill(pid, 0)
@@ -80,6 +101,26 @@ def test_child_that_dies_in_native_code_is_reported_by_exit_code(tmp_path):
   with pytest.raises(mpu.ChildException) as ei:
     mpu.multi_proc_run(2, fun=_die_without_traceback, fun_args=(str(tmp_path),))
   assert ei.value.rank == 0 and ei.value.exitcode == 7 and "code 7" in str(ei.value)
+
+
+def test_traceback_larger_than_the_pipe_buffer_does_not_hang(tmp_path):
+  """The parent reads a child's pipe while it waits, not after the child has exited (a 64 KiB pipe
+  buffer blocked the child's send for ever and the run hung instead of raising)."""
+  from pointcontrast_amd.lib import multiprocessing as mpu
+  t0 = time.time()
+  with pytest.raises(mpu.ChildException) as ei:
+    mpu.multi_proc_run(2, fun=_huge_traceback, fun_args=(str(tmp_path),))
+  assert time.time() - t0 < 60
+  assert ei.value.rank == 1 and len(str(ei.value)) > (1 << 20) and "ValueError" in str(ei.value)
+
+
+def test_sys_exit_zero_is_a_clean_exit_and_a_nonzero_code_is_kept(tmp_path):
+  from pointcontrast_amd.lib import multiprocessing as mpu
+  mpu.multi_proc_run(2, fun=_exit_zero, fun_args=(str(tmp_path),))  # must not raise
+  assert os.path.exists(tmp_path / "ran0") and os.path.exists(tmp_path / "ran1")
+  with pytest.raises(mpu.ChildException) as ei:
+    mpu.multi_proc_run(2, fun=_exit_five, fun_args=(str(tmp_path),))
+  assert ei.value.rank == 0 and ei.value.exitcode == 5 and "sys.exit(5)" in str(ei.value)
 
 
 SCRIPT = """
