@@ -12,6 +12,7 @@
 // kernels, no zero-fill of activation gradients).  Which is which is decided once, at creation.
 #include <algorithm>
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -49,6 +50,34 @@ struct HostProfile {
   }
 };
 static HostProfile g_prof_fwd, g_prof_bwd;
+
+// Host-side waits of the executor.  The wait in front of a forward pass for the previous pass's BatchNorm table is
+// what keeps the enqueueing thread one pass ahead of the GPU, i.e. the thread sits in it for about half of every
+// iteration.  Round 4 spun there (hipEventSynchronize: forward == forward_cpu == 8.9 ms of a 15.2 ms step in the
+// bench line -- a core per rank burnt; with 8 ranks x (enqueue + draw + RCCL proxy threads) that is 8 cores next to
+// the loader workers).  An event created with hipEventBlockingSync still spun on this driver (measured: same CPU time),
+// so the wait polls the event and SLEEPS in between (PCMI_THROTTLE_SLEEP_US, default 50; 0 = hipEventSynchronize):
+// the GPU is a whole backward pass behind the thread at that point, 50 us of wake-up latency cost nothing.
+static unsigned host_wait_event_flags() {
+  const char* e = getenv("PCMI_BLOCKING_EVENTS");  // 0: plain events (A/B)
+  return hipEventDisableTiming | ((e && e[0] == '0') ? 0u : (unsigned)hipEventBlockingSync);
+}
+static int host_wait_event(hipEvent_t ev) {
+  const char* e = getenv("PCMI_THROTTLE_SLEEP_US");
+  const long us = e ? atol(e) : 50;
+  if (us <= 0) {
+    PCMI_HIP_CHECK(hipEventSynchronize(ev));
+    return PCMI_OK;
+  }
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return PCMI_OK;
+    if (q != hipErrorNotReady) PCMI_HIP_CHECK(q);
+    (void)hipGetLastError();  // hipErrorNotReady is sticky in hipGetLastError: PCMI_LAUNCH_CHECK must not see it
+    struct timespec ts = {0, us * 1000L};
+    nanosleep(&ts, nullptr);
+  }
+}
 
 struct DevBuf {
   char* p = nullptr;
@@ -306,7 +335,7 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
       const int hs = ps.x3_jobs_slot;
       ps.x3_jobs_slot ^= 1;
       const size_t need = jobs.size() * sizeof(X3PackJob);
-      if (!ps.x3_jobs_copied[hs]) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_jobs_copied[hs], hipEventDisableTiming | hipEventBlockingSync));
+      if (!ps.x3_jobs_copied[hs]) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_jobs_copied[hs], host_wait_event_flags()));
       PCMI_HIP_CHECK(hipEventSynchronize(ps.x3_jobs_copied[hs]));  // the copy that last read this host buffer (two tables ago)
       if (need > ps.x3_jobs_host_cap[hs]) {
         if (ps.x3_jobs_host[hs]) PCMI_HIP_CHECK(hipHostFree(ps.x3_jobs_host[hs]));
@@ -793,12 +822,10 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       PCMI_HIP_CHECK(hipMalloc((void**)&ps.upd_dev, sizeof(BnRunningUpdate) * n_bn));
       ps.upd_cap = n_bn;
     }
-    // This wait is also what keeps the enqueueing thread ONE pass ahead of the GPU (the event sits behind the previous
-    // forward of this pass).  hipEventBlockingSync: the thread sleeps in the driver instead of spinning on the event --
-    // round 4's bench line had forward == forward_cpu == 8.9 ms of a 15.2 ms step, i.e. a core per rank burnt in this
-    // wait (with 8 ranks x (enqueue + draw + RCCL proxy threads) that is 8 cores spinning next to the loader workers).
-    if (!ps.upd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.upd_copied, hipEventDisableTiming | hipEventBlockingSync));
-    PCMI_HIP_CHECK(hipEventSynchronize(ps.upd_copied));  // the previous table has left the pinned buffer
+    // (this wait is also what keeps the enqueueing thread ONE pass ahead of the GPU: host_wait_event sleeps in it)
+    if (!ps.upd_copied) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.upd_copied, host_wait_event_flags()));
+    rc = host_wait_event(ps.upd_copied);  // the previous table has left the pinned buffer
+    if (rc) return rc;
   }
   ps.in_feats = in_feats;
   ps.in_ld = in_ld;

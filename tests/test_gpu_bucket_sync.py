@@ -155,7 +155,7 @@ def _two_rank_worker(out_dir):
     rec["skip"] = box.get("err", "gloo all-reduce of a device tensor did not finish within 90 s")
     json.dump(rec, open(os.path.join(out_dir, "rank%d.json" % rank), "w"))
     os._exit(0)  # (a helper thread may be stuck inside the collective)
-  batch = _batch(10 + rank)
+  batch = _batch((3, 5)[rank])  # (seeds whose 0.7 m crops are non-empty in both clouds)
   # (different initial weights per rank: only the broadcast of rank 0's makes them equal)
   tr = _trainer(batch, ["opt.lr=0.0", "opt.momentum=0.0", "opt.weight_decay=0.0", "misc.num_gpus=2", "trainer.batch_size=4"],
                 seed=7 + rank)
