@@ -177,9 +177,9 @@ struct pcmi_net {
   std::vector<pcmi::PassState> passes;
   // side: the weight gradients of a backward pass (off the critical path: nothing downstream reads them) at the lowest
   // stream priority, with a workspace of their own
-  // side[1] (PCMI_WGRAD_SIDE2=1, an experiment): the SMALL weight-gradient launches (levels under 8192 rows, strided and
-  // 1x1 layers: ~45 latency-bound launches per step that use a few dozen compute units each) on a stream of their own, so
-  // that they run beside the large level-1 launches instead of queueing behind them
+  // side[1] (PCMI_WGRAD_SIDE2=1, an experiment that lost: 254.4 against 260.2 pairs/s, profiles/r05a_*): the SMALL
+  // weight-gradient launches (levels under 8192 rows, strided and 1x1 layers: ~45 latency-bound launches per step that use
+  // a few dozen compute units each) on a stream of their own, beside the large level-1 launches instead of behind them
   static constexpr int kSides = 2;
   hipStream_t side[kSides] = {nullptr, nullptr};
   hipEvent_t ev_main[kSides] = {nullptr, nullptr}, ev_side[kSides] = {nullptr, nullptr};
@@ -408,8 +408,8 @@ static long debug_env_long(const char* name) {
   return e ? atol(e) : 0;
 }
 
-static int ensure_streams(pcmi_net& n) {
-  if (n.side[0]) return PCMI_OK;
+static int ensure_streams(pcmi_net& n, bool second) {
+  if (n.side[0] && (!second || n.side[1])) return PCMI_OK;
   // the weight gradients are off the critical path: lowest priority, so that the chain's kernels are dispatched
   // first and the weight-gradient workgroups fill what they leave idle (same priority measured: 17.5-19.4 against
   // 16.6 ms per iteration; weight gradients on the chain's own stream: 28 ms)
@@ -418,13 +418,19 @@ static int ensure_streams(pcmi_net& n) {
   // (a stream confined to a subset of the compute units -- hipExtStreamCreateWithCUMask, so that the chain's small
   //  kernels always find free units -- was tried: such a stream cannot be non-blocking and serialises against the
   //  caller's default stream, 165 against 253 pairs/s with any mask; profiles/r03j_bench_ab_cu_mask.txt)
-  for (int i = 0; i < pcmi_net::kSides; ++i) {
+  // The second side stream exists ONLY under PCMI_WGRAD_SIDE2=1.  Round 5 created it unconditionally for one GPU call
+  // (idle unless the switch was on) and the forced 1-rank reducer run went from 15.8 to 45 ms per step: with the
+  // reducer's communication stream it was one stream too many for the device's hardware queues, two of the executor's
+  // streams shared a queue and serialised (profiles/r05b_idle_second_side_stream_and_forced_reducer.txt).  Streams of
+  // a rank in the step: compute, plan, weight-gradient side, communication -- nothing else may be added casually.
+  for (int i = 0; i < (second ? pcmi_net::kSides : 1); ++i) {
+    if (n.side[i]) continue;
     PCMI_HIP_CHECK(hipStreamCreateWithPriority(&n.side[i], hipStreamNonBlocking, least));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_main[i], hipEventDisableTiming));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_side[i], hipEventDisableTiming));
     PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_side[i], hipEventDisableTiming));
   }
-  PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_main, hipEventDisableTiming));
+  if (!n.ev_bkt_main) PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_bkt_main, hipEventDisableTiming));
   return PCMI_OK;
 }
 
@@ -487,9 +493,9 @@ struct BackwardRun {
     rc = ps->small.reserve((size_t)4 * max_c * sizeof(float) + 256, st);  // per segment: dbeta, dgamma
     if (rc) return rc;
     scratch_g = (float*)ps->small.p;
-    rc = ensure_streams(n);
-    if (rc) return rc;
     two_sides = debug_env_long("PCMI_WGRAD_SIDE2") != 0;
+    rc = ensure_streams(n, two_sides);
+    if (rc) return rc;
     small_rows = 8192;  // (= the default of PCMI_WGRAD_X3T: what is under it takes the pair-list kernel)
     for (int q = 0; q < (two_sides ? 2 : 1); ++q) {
       rc = n.ws_side[q].reserve(ps->ws.cap, n.side[q]);

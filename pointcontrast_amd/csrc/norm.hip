@@ -540,6 +540,234 @@ __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restr
   }
 }
 
+// ---- small activations: the whole BatchNorm of a segment in ONE launch ---------------------------------------------
+// The coarse levels of the U-Net (strides 8 and 16: 400-1400 rows per cloud and level on the bench batch, 128-256
+// channels) run 30 of the network's 62 BatchNorms, each as three dependent launches per direction -- statistics over
+// per-block partials, their merge, the apply pass: 19 us forward / 23 us backward of kernels that move 0.4-1.4 MB, plus
+// two inter-kernel gaps on a chain that is latency-bound there.  With so few rows no cross-workgroup
+// reduction is needed at all: a workgroup owns 16 channels (four float4 columns = 64 contiguous bytes of every row) of
+// ALL rows of a segment, keeps its rows in registers (<= 12 per thread), reduces over its row lanes through shuffles
+// and LDS in a fixed order, and applies -- one launch, no partials, no hand-over.  The statistics are two-pass (mean,
+// then the centred second moment of the register-resident rows): at least as accurate as the merged partials.
+// Geometry: thread t -> column cg = t & 3, row lane rl = t >> 2 (RL = THREADS / 4 lanes); rows rl, rl + RL, ...;
+// grid = (c / 16, segments).  Eligible: c % 16 == 0 and <= kSmallMaxRows rows per segment (PCMI_BN_SMALL_ROWS).
+constexpr int kSmallCG = 4;
+constexpr int kSmallMaxRPT = 12;
+
+// sum over all row lanes of the workgroup, per column group: every thread returns the total of ITS column group.
+// Fixed order: xor-shuffles over the 16 row lanes of a wave, then the waves in index order.  s_w: [16][kSmallCG].
+__device__ __forceinline__ float4 small_block_sum(float4 v, float4 (*s_w)[kSmallCG], int t) {
+#pragma unroll
+  for (int d = 4; d < 64; d <<= 1) {
+    v.x += __shfl_xor(v.x, d, 64);
+    v.y += __shfl_xor(v.y, d, 64);
+    v.z += __shfl_xor(v.z, d, 64);
+    v.w += __shfl_xor(v.w, d, 64);
+  }
+  const int lane = t & 63, wave = t >> 6, nw = (int)blockDim.x >> 6;
+  __syncthreads();  // (the previous use of s_w)
+  if (lane < kSmallCG) s_w[wave][lane] = v;
+  __syncthreads();
+  float4 s = s_w[0][t & 3];
+  for (int w = 1; w < nw; ++w) {
+    const float4 o = s_w[w][t & 3];
+    s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+  }
+  return s;
+}
+
+struct BnSmallFwd {
+  const float* x; int64_t x_ld;
+  const float* res; int64_t res_ld;
+  float* y; int64_t y_ld;
+  int64_t n, split;  // split == n: one segment
+  const float* gamma; const float* beta;
+  int relu;
+  RedFinal fin;      // MODE 0 outputs (save_*, running_*, eps, momentum, out_seg_stride)
+};
+
+// Rows go through raw buffer loads / stores: ONE offset register per operand (row lane x leading dimension + the
+// thread's 16 bytes of the row), the row index j as a scalar offset -- so that the 12 rows a thread holds do not cost 12
+// 64-bit addresses per operand -- and a row past the segment is an out-of-range offset: it loads zeros and its store
+// is dropped (the scalar offset does not take part in the range check, so out of range stays out of range).
+typedef float sf4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kSmallOut = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t small_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4 small_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  const sf4 v = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void small_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float4& v) {
+  const sf4 t = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), r, voff, soff, 0);
+}
+
+template <int RPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_small_fwd_kernel(BnSmallFwd a) {
+  __shared__ float4 s_w[16][kSmallCG];
+  constexpr int RL = THREADS / kSmallCG;
+  const int t = threadIdx.x, cg = t & 3, rl = t >> 2;
+  const int sg = blockIdx.y;
+  const int64_t base = sg ? a.split : 0;
+  const int ns = (int)(gridDim.y > 1 ? (sg ? a.n - a.split : a.split) : a.n);
+  const int col4 = blockIdx.x * kSmallCG + cg;
+  RedFinal fin = a.fin;
+  if (sg) {
+    fin.save_mean += fin.out_seg_stride;
+    fin.save_invstd += fin.out_seg_stride;
+    if (fin.save_unbiased) fin.save_unbiased += fin.out_seg_stride;
+  }
+  const int cb = blockIdx.x * (4 * kSmallCG);  // first channel of the workgroup (uniform: part of the buffer base)
+  const __amdgpu_buffer_rsrc_t xr = small_rsrc(a.x + base * a.x_ld + cb), yr = small_rsrc(a.y + base * a.y_ld + cb);
+  const __amdgpu_buffer_rsrc_t rr = small_rsrc(a.res ? a.res + base * a.res_ld + cb : a.x);
+  const uint32_t xs = (uint32_t)a.x_ld * 4u, ys = (uint32_t)a.y_ld * 4u, rs = (uint32_t)a.res_ld * 4u;
+  const uint32_t xo = (uint32_t)rl * xs + (uint32_t)cg * 16u, yo = (uint32_t)rl * ys + (uint32_t)cg * 16u,
+                 ro = (uint32_t)rl * rs + (uint32_t)cg * 16u;
+  float4 xv[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) xv[j] = small_load(xr, rl + j * RL < ns ? xo : kSmallOut, (uint32_t)(j * RL) * xs);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) { s.x += xv[j].x; s.y += xv[j].y; s.z += xv[j].z; s.w += xv[j].w; }
+  s = small_block_sum(s, s_w, t);
+  const float cnt = (float)ns;
+  const float4 mean = make_float4(s.x / cnt, s.y / cnt, s.z / cnt, s.w / cnt);
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    if (rl + j * RL < ns) {  // (rows past the segment were loaded as zeros: they must not count as -mean)
+      const float dx = xv[j].x - mean.x, dy = xv[j].y - mean.y, dz = xv[j].z - mean.z, dw = xv[j].w - mean.w;
+      q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+    }
+  }
+  q = small_block_sum(q, s_w, t);
+  if (rl == 0) colreduce_write<0>(fin, col4, mean, q, cnt);  // mean, invstd, unbiased variance, running estimates
+  const float4 is = bn_invstd(q, cnt, fin.eps);
+  const float4 g = reinterpret_cast<const float4*>(a.gamma)[col4], b = reinterpret_cast<const float4*>(a.beta)[col4];
+  const bool has_res = a.res != nullptr;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const bool ok = rl + j * RL < ns;
+    float4 o;  // (the expression of bn_apply_kernel)
+    o.x = (xv[j].x - mean.x) * is.x * g.x + b.x;
+    o.y = (xv[j].y - mean.y) * is.y * g.y + b.y;
+    o.z = (xv[j].z - mean.z) * is.z * g.z + b.z;
+    o.w = (xv[j].w - mean.w) * is.w * g.w + b.w;
+    if (has_res) {  // (uniform)
+      const float4 rv = small_load(rr, ok ? ro : kSmallOut, (uint32_t)(j * RL) * rs);
+      o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+    }
+    if (a.relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    small_store(yr, ok ? yo : kSmallOut, (uint32_t)(j * RL) * ys, o);
+  }
+}
+
+struct BnSmallBwd {
+  const float* dy; int64_t dy_ld;
+  const float* x; int64_t x_ld;
+  const float* ymask; int64_t y_ld;  // nullable
+  int64_t n, split;                  // split == n: one segment
+  const float* gamma;
+  const float* mean; const float* invstd; int stat_stride;  // floats between the segments' statistics
+  float* dx; int64_t dx_ld;
+  float* dres; int64_t dres_ld; int dres_accumulate;        // nullable
+  float* sum_g; float* sum_gx; int sum_stride;              // this call's sums per segment (dbeta, dgamma)
+  float* acc_g; float* acc_gx;                               // nullable: parameter gradients, += segment 0, then += segment 1
+};
+
+// The segments of a two-segment tensor are handled ONE AFTER THE OTHER by the same workgroup: the parameter gradients
+// are (acc + sums of segment 0) + sums of segment 1, in that order -- what two consecutive one-segment calls accumulate
+// (and what bn_bwd_apply_kernel does) -- without a hand-over between workgroups.
+template <int RPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
+  __shared__ float4 s_w[16][kSmallCG];
+  constexpr int RL = THREADS / kSmallCG;
+  const int t = threadIdx.x, cg = t & 3, rl = t >> 2;
+  const int col4 = blockIdx.x * kSmallCG + cg;
+  const int cb = blockIdx.x * (4 * kSmallCG);
+  const int n_seg = a.split < a.n ? 2 : 1;
+  const float4 ga = reinterpret_cast<const float4*>(a.gamma)[col4];
+  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+  if (a.acc_g && rl == 0) {
+    pa = reinterpret_cast<const float4*>(a.acc_g)[col4];
+    pb = reinterpret_cast<const float4*>(a.acc_gx)[col4];
+  }
+  const uint32_t gs = (uint32_t)a.dy_ld * 4u, xs = (uint32_t)a.x_ld * 4u, ys = (uint32_t)a.y_ld * 4u, ds = (uint32_t)a.dx_ld * 4u,
+                 rs = (uint32_t)a.dres_ld * 4u;
+  const uint32_t lane_b = (uint32_t)cg * 16u;
+  const bool masked = a.ymask != nullptr, has_res = a.dres != nullptr;
+#pragma unroll 1
+  for (int sg = 0; sg < n_seg; ++sg) {
+    const int64_t base = sg ? a.split : 0;
+    const int ns = (int)(n_seg > 1 ? (sg ? a.n - a.split : a.split) : a.n);
+    const float4 mu = reinterpret_cast<const float4*>(a.mean + sg * a.stat_stride)[col4];
+    const float4 is = reinterpret_cast<const float4*>(a.invstd + sg * a.stat_stride)[col4];
+    const __amdgpu_buffer_rsrc_t gr = small_rsrc(a.dy + base * a.dy_ld + cb), xr = small_rsrc(a.x + base * a.x_ld + cb);
+    const __amdgpu_buffer_rsrc_t yr = small_rsrc(masked ? a.ymask + base * a.y_ld + cb : a.x);
+    const __amdgpu_buffer_rsrc_t dr = small_rsrc(a.dx + base * a.dx_ld + cb);
+    const __amdgpu_buffer_rsrc_t rr = small_rsrc(has_res ? a.dres + base * a.dres_ld + cb : a.dx);
+    float4 gm[RPT], xh[RPT];  // masked gradient, normalised input
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const bool ok = rl + j * RL < ns;
+      gm[j] = small_load(gr, ok ? (uint32_t)rl * gs + lane_b : kSmallOut, (uint32_t)(j * RL) * gs);
+      xh[j] = small_load(xr, ok ? (uint32_t)rl * xs + lane_b : kSmallOut, (uint32_t)(j * RL) * xs);
+    }
+    if (masked) {  // (uniform)
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {  // (a row past the segment: gm is zero already, whatever its mask reads)
+        const float4 yv = small_load(yr, rl + j * RL < ns ? (uint32_t)rl * ys + lane_b : kSmallOut, (uint32_t)(j * RL) * ys);
+        gm[j].x = yv.x > 0.f ? gm[j].x : 0.f; gm[j].y = yv.y > 0.f ? gm[j].y : 0.f;
+        gm[j].z = yv.z > 0.f ? gm[j].z : 0.f; gm[j].w = yv.w > 0.f ? gm[j].w : 0.f;
+      }
+    }
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {  // (a row past the segment: x read as zero, but gm = 0: it adds nothing to either sum)
+      xh[j] = make_float4((xh[j].x - mu.x) * is.x, (xh[j].y - mu.y) * is.y, (xh[j].z - mu.z) * is.z, (xh[j].w - mu.w) * is.w);
+      sa.x += gm[j].x; sa.y += gm[j].y; sa.z += gm[j].z; sa.w += gm[j].w;
+      sb.x = fmaf(gm[j].x, xh[j].x, sb.x); sb.y = fmaf(gm[j].y, xh[j].y, sb.y);
+      sb.z = fmaf(gm[j].z, xh[j].z, sb.z); sb.w = fmaf(gm[j].w, xh[j].w, sb.w);
+    }
+    sa = small_block_sum(sa, s_w, t);
+    sb = small_block_sum(sb, s_w, t);
+    if (rl == 0) {
+      reinterpret_cast<float4*>(a.sum_g + sg * a.sum_stride)[col4] = sa;
+      reinterpret_cast<float4*>(a.sum_gx + sg * a.sum_stride)[col4] = sb;
+      pa = make_float4(pa.x + sa.x, pa.y + sa.y, pa.z + sa.z, pa.w + sa.w);
+      pb = make_float4(pb.x + sb.x, pb.y + sb.y, pb.z + sb.z, pb.w + sb.w);
+    }
+    const float inv_n = 1.0f / (float)ns;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const bool ok = rl + j * RL < ns;
+      float4 o;  // (the expression of bn_bwd_apply_kernel; xh = (x - mean) * invstd)
+      o.x = ga.x * is.x * (gm[j].x - sa.x * inv_n - xh[j].x * sb.x * inv_n);
+      o.y = ga.y * is.y * (gm[j].y - sa.y * inv_n - xh[j].y * sb.y * inv_n);
+      o.z = ga.z * is.z * (gm[j].z - sa.z * inv_n - xh[j].z * sb.z * inv_n);
+      o.w = ga.w * is.w * (gm[j].w - sa.w * inv_n - xh[j].w * sb.w * inv_n);
+      small_store(dr, ok ? (uint32_t)rl * ds + lane_b : kSmallOut, (uint32_t)(j * RL) * ds, o);
+      if (has_res) {  // (uniform)
+        float4 g = gm[j];
+        const uint32_t vo = ok ? (uint32_t)rl * rs + lane_b : kSmallOut;
+        if (a.dres_accumulate) {
+          const float4 old = small_load(rr, vo, (uint32_t)(j * RL) * rs);
+          g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
+        }
+        small_store(rr, vo, (uint32_t)(j * RL) * rs, g);
+      }
+    }
+  }
+  if (a.acc_g && rl == 0) {
+    reinterpret_cast<float4*>(a.acc_g)[col4] = pa;
+    reinterpret_cast<float4*>(a.acc_gx)[col4] = pb;
+  }
+}
+
 // y = relu?( (x - mean) * (invstd * gamma) + beta (+ residual) )
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t x_ld,
                                                        int64_t n, int c4, const float* __restrict__ gamma,
@@ -711,6 +939,54 @@ static bool bn_lean_eligible(int64_t n, int c, int64_t x_ld, int64_t dy_ld, int6
   return lean > 0 && n >= lean && c % 2 == 0 && c / 2 <= 256 && n * ld * 4 <= 0x7FFFFF00ll;  // 32-bit byte offsets
 }
 
+// PCMI_BN_SMALL_ROWS: up to this many rows per segment a BatchNorm runs as ONE launch per direction (bn_small_*_kernel);
+// 0 = never.  Read per call.  The bound of the kernels is 128 row lanes x 12 rows.
+static int64_t bn_small_rows() {
+  const char* e = getenv("PCMI_BN_SMALL_ROWS");
+  const int64_t v = e ? (int64_t)atoll(e) : (int64_t)1536;
+  return std::min<int64_t>(v, 128 * kSmallMaxRPT);
+}
+static bool bn_small_eligible(int64_t longest_segment, int c) {
+  return longest_segment > 0 && longest_segment <= bn_small_rows() && c % (4 * kSmallCG) == 0;
+}
+#define PCMI_BN_SMALL_DISPATCH(KERNEL, ARGS, GRID, LONGEST, ST)                                   \
+  do {                                                                                            \
+    const bool wide = (LONGEST) > 64 * kSmallMaxRPT;                                              \
+    const int rl = wide ? 128 : 64;                                                               \
+    const int need = (int)ceil_div((LONGEST), rl);                                                \
+    if (!wide) {                                                                                  \
+      if (need <= 4) KERNEL<4, 256><<<GRID, 256, 0, ST>>>(ARGS);                                   \
+      else if (need <= 8) KERNEL<8, 256><<<GRID, 256, 0, ST>>>(ARGS);                              \
+      else KERNEL<12, 256><<<GRID, 256, 0, ST>>>(ARGS);                                            \
+    } else {                                                                                      \
+      if (need <= 8) KERNEL<8, 512><<<GRID, 512, 0, ST>>>(ARGS);                                   \
+      else KERNEL<12, 512><<<GRID, 512, 0, ST>>>(ARGS);                                            \
+    }                                                                                             \
+  } while (0)
+
+static int bn_small_forward(const float* x, int64_t x_ld, int64_t n, int64_t split, int c, const float* gamma, const float* beta,
+                            const float* residual, int64_t res_ld, int relu, float* y, int64_t y_ld, const RedFinal& fin,
+                            hipStream_t st) {
+  BnSmallFwd a;
+  a.x = x; a.x_ld = x_ld; a.res = residual; a.res_ld = res_ld; a.y = y; a.y_ld = y_ld;
+  a.n = n; a.split = split; a.gamma = gamma; a.beta = beta; a.relu = relu; a.fin = fin;
+  const bool two = split < n;
+  const int64_t longest = two ? std::max(split, n - split) : n;
+  const dim3 grid((unsigned)(c / (4 * kSmallCG)), two ? 2u : 1u);
+  PCMI_BN_SMALL_DISPATCH(bn_small_fwd_kernel, a, grid, longest, st);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+static int bn_small_backward(const BnSmallBwd& a, int c, hipStream_t st) {
+  const bool two = a.split < a.n;
+  const int64_t longest = two ? std::max(a.split, a.n - a.split) : a.n;
+  const dim3 grid((unsigned)(c / (4 * kSmallCG)));
+  PCMI_BN_SMALL_DISPATCH(bn_small_bwd_kernel, a, grid, longest, st);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
 static bool fuse_final_enabled() {
   static const bool on = [] {
     const char* e = getenv("PCMI_BN_FUSED_FINAL");
@@ -777,6 +1053,7 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
   fin.save_mean = save_mean;
   fin.save_invstd = save_invstd;
   fin.save_unbiased = save_unbiased;
+  if (bn_small_eligible(n, c)) return bn_small_forward(x, x_ld, n, n, c, gamma, beta, residual, res_ld, relu, y, y_ld, fin, st);
   if (fuse) {  // statistics + their final merge in ONE launch (last-arriving workgroup), then the apply pass
     fin.counter = stream_counters(st, 1);
     if (!fin.counter) return PCMI_ERR_HIP;
@@ -833,6 +1110,10 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
   fin.save_invstd = save_invstd;
   fin.save_unbiased = save_unbiased;
   fin.out_seg_stride = stat_stride;
+  if (bn_small_eligible(longest, c)) {
+    fin.counter = nullptr;
+    return bn_small_forward(x, x_ld, n, split, c, gamma, beta, residual, res_ld, relu, y, y_ld, fin, st);
+  }
   const int64_t part_seg = (int64_t)g.nblocks * 2 * c;
 #if defined(PCMI_BN_DIAG_SKIP_SMALL_STATS)  // timing diagnostic (wrong results): as if the producer had left the partials behind
   if (longest >= PCMI_BN_DIAG_SKIP_SMALL_STATS)
@@ -878,6 +1159,14 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
+  if (bn_small_eligible(longest, c)) {
+    BnSmallBwd a;
+    a.dy = dy; a.dy_ld = dy_ld; a.x = x; a.x_ld = x_ld; a.ymask = relu_mask_y; a.y_ld = y_ld; a.n = n; a.split = split;
+    a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd; a.stat_stride = stat_stride;
+    a.dx = dx; a.dx_ld = dx_ld; a.dres = dres; a.dres_ld = dres_ld; a.dres_accumulate = dres_accumulate;
+    a.sum_g = sums; a.sum_gx = sums + c; a.sum_stride = 2 * c; a.acc_g = acc_dbeta; a.acc_gx = acc_dgamma;
+    return bn_small_backward(a, c, st);
+  }
   const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
   const bool fuse = fuse_final_enabled() && !lean;  // (the lean statistics kernel never merges: it has no registers for it)
   if (fuse) {
@@ -980,6 +1269,14 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
+  if (bn_small_eligible(n, c)) {
+    BnSmallBwd a;
+    a.dy = dy; a.dy_ld = dy_ld; a.x = x; a.x_ld = x_ld; a.ymask = relu_mask_y; a.y_ld = y_ld; a.n = n; a.split = n;
+    a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd; a.stat_stride = 0;
+    a.dx = dx; a.dx_ld = dx_ld; a.dres = dres; a.dres_ld = dres_ld; a.dres_accumulate = dres_accumulate;
+    a.sum_g = dbeta; a.sum_gx = dgamma; a.sum_stride = 0; a.acc_g = acc_dbeta; a.acc_gx = acc_dgamma;
+    return bn_small_backward(a, c, st);
+  }
   const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
   const bool small = g.nblocks <= kFuseFinalBlocks, fuse = small && fuse_final_enabled() && !lean;
   fin.out_a = dbeta;

@@ -339,15 +339,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
     // of tile + 2 are requested in a tile's last step and converted in the next tile's second.
     static_assert(KG == 4, "one register set per offset slot");
     Row r0[8], r1[8], r2[8], r3[8], rgv[8];
-    // Requests are UNCONDITIONAL: an absent slot has nothing but out-of-range offsets in its table (no memory traffic,
-    // zeros come back).  With the requests under `if (present)` the compiler cannot pair a request with its conversion
-    // (two reads of the same flag), assumes requests that were never consumed and guards every reuse of the ring
-    // registers with s_waitcnt vmcnt(0) -- which exposes the latency of the gathers it has just issued.
-    // Round 5: the CONVERSION of an absent slot is skipped (round 4 converted its zeros like any other slot, "a few
-    // hundred wasted VALU cycles in waves that have slack" -- but the producers are what bounds this kernel, every
-    // slot cost the same 1.44 us whether or not its offset occurs in the tile, and 39 % of the slots of the bench
-    // batch are absent).  Both paths have issued the same loads, so the wait counts stay immediates (hipcc -S: the
-    // loop's waits are vmcnt(16..31) as before, no vmcnt(0)).
+    // Requests and conversions are UNCONDITIONAL: an absent slot has nothing but out-of-range offsets in its table (no
+    // memory traffic, zeros come back) and is converted like any other -- a few hundred wasted VALU cycles in waves that
+    // have slack.  With the requests under `if (present)` the compiler cannot pair a request with its conversion (two
+    // reads of the same flag), assumes requests that were never consumed and guards every reuse of the ring registers
+    // with s_waitcnt vmcnt(0) -- which exposes the latency of the gathers it has just issued.
+    // Round 5 measured the other half: ONLY the conversion under a wave-uniform `if (slot present)` (requests still
+    // unconditional; hipcc -S: no vmcnt(0), the loop's waits stay vmcnt(16..31), 230 registers as before).  39 % of the
+    // slots of the bench batch are absent, so this removes 39 % of the producers' split work -- and the kernel got
+    // SLOWER: level-1 96 -> 96 0.498 -> 0.537 ms, level 2 0.130 -> 0.138 ms, the step unchanged (264.1 vs 265.0
+    // pairs/s, inside the run-to-run spread): profiles/r05b_wgrad_x3p_skip_absent_conversion_ab.txt.  The conversion of
+    // zeros in an absent slot is NOT what the kernel waits for (the consumers have nothing to do in such a slot and
+    // the producers' next request has been in flight for two steps); the present slots are, where a producer's
+    // conversion and a consumer's 36 fragment reads + 108 products share a SIMD and the LDS pipe.
     table_issue(0);
     table_commit(0);
     table_issue(1);
@@ -370,19 +374,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
           const int s3 = (sx + 3) % KG, tl3 = tl + (sx + 3) / KG;
           issue(PCMI_X3P_SET(s3), xr, s_xoff[tl3 % 3][s3], c0, kWX);
         }
-        // slot q + 1 (requested two steps ago): convert and write into the X buffer the consumers are not reading -- unless
-        // the slot is absent (its rows came back as zeros and no consumer will read the buffer: s_any guards the products).
-        // Only the CONVERSION is conditional; the request above stays unconditional, so both paths have issued the same
-        // loads and the wait counts stay immediates (see the note at the register sets).
-        {
-          const int s1 = (sx + 1) % KG, tl1 = tl + (sx + 1) / KG;
-#if defined(PCMI_X3P_CONVERT_ABSENT)  // A/B build: round 4's form (every slot converted, absent ones convert zeros)
-          (void)tl1;
-          finish(s_x[(sx + 1) & 1], PCMI_X3P_SET(s1), kWX);
-#else
-          if (__builtin_amdgcn_readfirstlane(s_any[tl1 % 3][s1]) != 0) finish(s_x[(sx + 1) & 1], PCMI_X3P_SET(s1), kWX);
-#endif
-        }
+        // slot q + 1 (requested two steps ago): convert and write into the X buffer the consumers are not reading
+        finish(s_x[(sx + 1) & 1], PCMI_X3P_SET((sx + 1) % KG), kWX);
         if (sx == 1) finish(s_g[(tl + 1) & 1], rgv, kWG);
         if (sx == KG - 2) table_commit(tl + 2);  // (first read one step on: a barrier away)
         if (sx == KG - 1) issue(rgv, gr, s_goff[(tl + 2) % 3], n0, kWG);  // (its table: written one step ago)

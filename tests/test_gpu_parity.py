@@ -349,7 +349,11 @@ def test_spconv_golden(ME):
 # ------------------------------------------------------------------------------------------------
 # normalisation / elementwise
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,c", [(1, 32), (77, 32), (1728, 96), (5000, 96), (40000, 128), (3000, 256), (90000, 32)])
+@pytest.mark.parametrize("n,c", [(1, 32), (77, 32), (1728, 96), (5000, 96), (40000, 128), (3000, 256), (90000, 32),
+                                 # the one-launch form (csrc/norm.hip::bn_small_*_kernel: <= 1536 rows, c % 16 == 0) around its
+                                 # row-lane / rows-per-thread boundaries (64 x 4, 64 x 8, 64 x 12 = 768, 128 x 8, 128 x 12)
+                                 (65, 16), (256, 64), (257, 128), (512, 256), (768, 128), (769, 256), (1024, 32), (1400, 256),
+                                 (1536, 96), (1537, 96)])
 @pytest.mark.parametrize("fused", [False, True])
 def test_batchnorm_parity(n, c, fused):
   from pointcontrast_amd import functional as PF
@@ -428,6 +432,28 @@ def test_batchnorm_backward_lean_statistics_match_the_wide_kernel(n, c, monkeypa
     assert_close(out["1"][i], ref[i], 1e-4, "lean bn %s vs float64" % what)
     assert_close(out["1"][i], out["0"][i], 1e-5, "lean vs wide bn %s" % what)
   assert torch.equal(out["1"][3], out["0"][3])  # the residual gradient does not depend on the sums
+
+
+@pytest.mark.parametrize("n,c", [(300, 64), (768, 256), (1350, 128), (1536, 256)])
+def test_batchnorm_one_launch_form_matches_the_three_launch_form(n, c, monkeypatch):
+  """bn_small_fwd / bwd_kernel (a workgroup owns 16 channels of all rows: statistics, merge and apply in one launch)
+  against the general path (per-block partials -> merge -> apply) on the same inputs: the same expressions on statistics
+  that differ by their summation order only."""
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(n * 7 + c)
+  x, res, gy = torch.randn(n, c) * 1.5 - 0.3, torch.randn(n, c), torch.randn(n, c)
+  gam, bet = torch.rand(c) + 0.5, torch.rand(c) - 0.5
+  out = {}
+  for rows in ("0", "1536"):
+    monkeypatch.setenv("PCMI_BN_SMALL_ROWS", rows)  # read per call
+    xd, rd = x.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+    g, b = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    y = PF.BatchNormFunction.apply(xd, g, b, rm, rv, 0.05, 1e-5, rd, True)
+    y.backward(gy.to(DEV))
+    out[rows] = [t_.detach().cpu() for t_ in (y, rm, rv, xd.grad, g.grad, b.grad, rd.grad)]
+  for i, what in enumerate(("y", "running mean", "running var", "dx", "dgamma", "dbeta", "dres")):
+    assert_close(out["1536"][i], out["0"][i], 2e-6 if i < 3 or i == 6 else 1e-5, "one-launch vs three-launch bn %s" % what)
 
 
 def test_bn_eval_relu_add_l2norm():
