@@ -599,9 +599,14 @@ __device__ __forceinline__ float4 small_load(__amdgpu_buffer_rsrc_t r, uint32_t 
   const sf4 v = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
   return make_float4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ void small_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float4& v) {
+// Stores take the WHOLE offset in the vector register (scalar offset 0).  With the row index as a scalar offset, as the
+// loads have it, buffer_store_dwordx4 wrote a stale second dword in lanes 12-15 of every 16 (measured on MI355X, round 5:
+// scripts/debug/bn_small_probe.py -- every row >= 64 with row % 4 == 3 had a wrong .y, plain pointer stores of the same
+// registers were right): the store's data registers are written by VALU instructions right in front of it, and the
+// compiler's hazard recogniser inserts the wait state for a > 64-bit MUBUF store only when soffset is NOT a register.
+__device__ __forceinline__ void small_store(__amdgpu_buffer_rsrc_t r, uint32_t voff, const float4& v) {
   const sf4 t = {v.x, v.y, v.z, v.w};
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, t), r, voff, 0, 0);
 }
 
 template <int RPT, int THREADS>
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(THREADS) void bn_small_fwd_kernel(BnSmallFwd a) {
     if (a.relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
-    small_store(yr, ok ? yo : kSmallOut, (uint32_t)(j * RL) * ys, o);
+    small_store(yr, ok ? yo + (uint32_t)(j * RL) * ys : kSmallOut, o);
   }
 }
 
@@ -750,15 +755,15 @@ __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
       o.y = ga.y * is.y * (gm[j].y - sa.y * inv_n - xh[j].y * sb.y * inv_n);
       o.z = ga.z * is.z * (gm[j].z - sa.z * inv_n - xh[j].z * sb.z * inv_n);
       o.w = ga.w * is.w * (gm[j].w - sa.w * inv_n - xh[j].w * sb.w * inv_n);
-      small_store(dr, ok ? (uint32_t)rl * ds + lane_b : kSmallOut, (uint32_t)(j * RL) * ds, o);
+      small_store(dr, ok ? (uint32_t)(rl + j * RL) * ds + lane_b : kSmallOut, o);
       if (has_res) {  // (uniform)
         float4 g = gm[j];
-        const uint32_t vo = ok ? (uint32_t)rl * rs + lane_b : kSmallOut;
+        const uint32_t vo = ok ? (uint32_t)(rl + j * RL) * rs + lane_b : kSmallOut;
         if (a.dres_accumulate) {
-          const float4 old = small_load(rr, vo, (uint32_t)(j * RL) * rs);
+          const float4 old = small_load(rr, vo, 0u);
           g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
         }
-        small_store(rr, vo, (uint32_t)(j * RL) * rs, g);
+        small_store(rr, vo, g);
       }
     }
   }

@@ -220,6 +220,40 @@ class GatherRowsFunction(Function):
     return dsrc, None
 
 
+class GatherPairFunction(Function):
+  """(F[idx_a], F[idx_b]) of ONE feature matrix -- the two clouds of a pair run as one two-segment tensor
+  (lib/ddp_trainer.py: misc.joint_pair), idx_b already shifted past the first cloud's rows -- with both gradients scattered
+  into ONE zero-filled buffer.  Through two GatherRowsFunction calls on the slices F[:n0] / F[n0:] autograd enqueued nine
+  kernels between the loss and the backward pass (two fills + two scatters of the halves, two more full-size fills + two
+  slice copies + an add: 92 us on the chain in profiles/r04zy_*); here: one fill, two scatters into disjoint row ranges."""
+
+  @staticmethod
+  def forward(ctx, src, idx_a, idx_b):
+    require_cuda(src, "gather pair")
+    src = _c(src)
+    idx_a = idx_a.to(device=src.device, dtype=torch.int64).contiguous()
+    idx_b = idx_b.to(device=src.device, dtype=torch.int64).contiguous()
+    c = src.shape[1]
+    outs = []
+    for idx in (idx_a, idx_b):
+      out = torch.empty((idx.shape[0], c), dtype=torch.float32, device=src.device)
+      check(lib.pcmi_gather_rows(ptr(src), src.stride(0), ptr(idx), idx.shape[0], c, ptr(out), c, cur_stream(src.device)))
+      outs.append(out)
+    ctx.save_for_backward(idx_a, idx_b)
+    ctx.n_src = src.shape[0]
+    return outs[0], outs[1]
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, da, db):
+    idx_a, idx_b = ctx.saved_tensors
+    c = da.shape[1]
+    dsrc = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=da.device)
+    for idx, d in ((idx_a, _c(da)), (idx_b, _c(db))):  # (the scatter owns every destination row it touches: order-free)
+      check(lib.pcmi_scatter_add_rows(ptr(d), d.stride(0), ptr(idx), d.shape[0], c, ptr(dsrc), c, cur_stream(d.device)))
+    return dsrc, None, None
+
+
 class NCELossFunction(Function):
   """mean_i(logsumexp_j(q_i.k_j/T) - q_i.k_i/T) without materialising the logits
   (torch.mm + CrossEntropyLoss at pc/lib/ddp_trainer.py:419-426)."""

@@ -634,9 +634,19 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
       sel = self.select_pairs_device(prep["input"]["correspondences"], self.npos, draws, slot, defer_wait=True)
       if sel is not None:
         prep["q_idx"], prep["k_idx"], prep["sel_event"] = sel
+        if "n0" in prep:  # the pair as one tensor: the keys' rows in it (PF.GatherPairFunction), still on the planning stream
+          from ..runtime import handle_pool
+          plan, cur = handle_pool.plan_stream(self.cur_device), torch.cuda.current_stream(self.cur_device)
+          with torch.cuda.stream(plan):
+            prep["k_idx_joint"] = prep["k_idx"] + prep["n0"]
+            prep["sel_event"] = torch.cuda.Event()
+            prep["sel_event"].record(plan)
+          prep["k_idx_joint"].record_stream(cur)
         return
     q_idx, k_idx = self.select_pairs(prep["input"]["correspondences"], self.npos, draws)
     prep["q_idx"], prep["k_idx"] = self._upload(q_idx, slot), self._upload(k_idx, slot + 1)
+    if "n0" in prep:
+      prep["k_idx_joint"] = self._upload(k_idx + prep["n0"], slot + 4)
 
   def _train_iter(self, data_loader_iter, timers, draws=None):
     self.model.train()
@@ -652,8 +662,12 @@ class PointNCELossTrainer(ContrastiveLossTrainer):
     mark("forward")
     if prep.get("sel_event") is not None:  # the pair selection ran on the planning stream (select_pairs_device)
       torch.cuda.current_stream(self.cur_device).wait_event(prep["sel_event"])
-    q = PF.GatherRowsFunction.apply(F0, prep["q_idx"])
-    k = PF.GatherRowsFunction.apply(F1, prep["k_idx"])
+    if "k_idx_joint" in prep and len(self._feats) == 1 and self.config.misc.get("fused_pair_gather", True):
+      # both gathers from the pair's ONE feature matrix, both gradients into one buffer (no slice / accumulate kernels)
+      q, k = PF.GatherPairFunction.apply(self._feats[0], prep["q_idx"], prep["k_idx_joint"])
+    else:
+      q = PF.GatherRowsFunction.apply(F0, prep["q_idx"])
+      k = PF.GatherRowsFunction.apply(F1, prep["k_idx"])
     loss = PF.NCELossFunction.apply(q, k, self.T)
     mark("loss")
     result = self._backward_and_step(loss, {"loss": loss.detach()})
