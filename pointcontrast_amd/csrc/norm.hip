@@ -944,16 +944,21 @@ static bool bn_lean_eligible(int64_t n, int c, int64_t x_ld, int64_t dy_ld, int6
   return lean > 0 && n >= lean && c % 2 == 0 && c / 2 <= 256 && n * ld * 4 <= 0x7FFFFF00ll;  // 32-bit byte offsets
 }
 
-// PCMI_BN_SMALL_ROWS: up to this many rows per segment a BatchNorm runs as ONE launch per direction (bn_small_*_kernel);
-// 0 = never.  Read per call.  The bound of the kernels is 128 row lanes x 12 rows.
-static int64_t bn_small_rows() {
-  const char* e = getenv("PCMI_BN_SMALL_ROWS");
-  const int64_t v = e ? (int64_t)atoll(e) : (int64_t)1536;
+// PCMI_BN_SMALL_ROWS / PCMI_BN_SMALL_BWD_ROWS: up to this many rows per segment a BatchNorm runs as ONE launch
+// (bn_small_fwd_kernel / bn_small_bwd_kernel); 0 = never.  Read per call.  The bound of the kernels is 128 row lanes x 12
+// rows.  Defaults 1536 forward, 768 backward -- measured on the bench batch (profiles/r05e_*): the forward kernel takes
+// 6.1 us at 403 rows per segment and 9.3 us at 1350 (three launches: ~19 us + two gaps); the backward kernel, which
+// walks the two segments of a pair one after the other (the parameter gradients are (acc + segment 0) + segment 1),
+// 12.6 us at 403 rows but 32.6 us at 1350 -- slower than the three launches it replaces (~24 us).
+static int64_t bn_small_rows(bool backward) {
+  const char* e = getenv(backward ? "PCMI_BN_SMALL_BWD_ROWS" : "PCMI_BN_SMALL_ROWS");
+  const int64_t v = e ? (int64_t)atoll(e) : (int64_t)(backward ? 768 : 1536);
   return std::min<int64_t>(v, 128 * kSmallMaxRPT);
 }
-static bool bn_small_eligible(int64_t longest_segment, int c) {
-  return longest_segment > 0 && longest_segment <= bn_small_rows() && c % (4 * kSmallCG) == 0;
+static bool bn_small_eligible(int64_t longest_segment, int c, bool backward = false) {
+  return longest_segment > 0 && longest_segment <= bn_small_rows(backward) && c % (4 * kSmallCG) == 0;
 }
+
 #define PCMI_BN_SMALL_DISPATCH(KERNEL, ARGS, GRID, LONGEST, ST)                                   \
   do {                                                                                            \
     const bool wide = (LONGEST) > 64 * kSmallMaxRPT;                                              \
@@ -1164,7 +1169,7 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  if (bn_small_eligible(longest, c)) {
+  if (bn_small_eligible(longest, c, true)) {
     BnSmallBwd a;
     a.dy = dy; a.dy_ld = dy_ld; a.x = x; a.x_ld = x_ld; a.ymask = relu_mask_y; a.y_ld = y_ld; a.n = n; a.split = split;
     a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd; a.stat_stride = stat_stride;
@@ -1274,7 +1279,7 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  if (bn_small_eligible(n, c)) {
+  if (bn_small_eligible(n, c, true)) {
     BnSmallBwd a;
     a.dy = dy; a.dy_ld = dy_ld; a.x = x; a.x_ld = x_ld; a.ymask = relu_mask_y; a.y_ld = y_ld; a.n = n; a.split = n;
     a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd; a.stat_stride = 0;

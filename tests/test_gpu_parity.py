@@ -355,8 +355,9 @@ def test_spconv_golden(ME):
                                  (65, 16), (256, 64), (257, 128), (512, 256), (768, 128), (769, 256), (1024, 32), (1400, 256),
                                  (1536, 96), (1537, 96)])
 @pytest.mark.parametrize("fused", [False, True])
-def test_batchnorm_parity(n, c, fused):
+def test_batchnorm_parity(n, c, fused, monkeypatch):
   from pointcontrast_amd import functional as PF
+  monkeypatch.setenv("PCMI_BN_SMALL_BWD_ROWS", "1536")  # (default 768: the backward kernel is tested over its whole range)
   if n == 1:
     pytest.skip("single-row batch norm is degenerate (var = 0) in torch too")
   torch.manual_seed(n + c)
@@ -446,6 +447,7 @@ def test_batchnorm_one_launch_form_matches_the_three_launch_form(n, c, monkeypat
   out = {}
   for rows in ("0", "1536"):
     monkeypatch.setenv("PCMI_BN_SMALL_ROWS", rows)  # read per call
+    monkeypatch.setenv("PCMI_BN_SMALL_BWD_ROWS", rows)
     xd, rd = x.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
     g, b = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
     rm, rv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
