@@ -188,6 +188,8 @@ struct pcmi_net {
   hipEvent_t ev_bkt_main = nullptr, ev_bkt_side[kSides] = {nullptr, nullptr};
   bool bkt_valid = false, bkt_side[kSides] = {false, false};
   pcmi::DevBuf ws_side[kSides];
+  // weight gradients of the coarse levels collected for ONE launch per run of layers (spconv_wgrad.hip: wgrad_group_*)
+  pcmi::WgradGroupBuilder* wgroup = nullptr;
   int64_t param_extent = 0;  // floats covered by the ops' parameters (rounded up to 4)
   // pcmi_net_time_ops: timing events around the convolution launches of selected ops INSIDE the passes (bench.py:
   // roofline.in_step_ms -- what the dominant kernel costs where it runs, next to the other streams, not stand-alone)
@@ -215,6 +217,7 @@ struct pcmi_net {
   ~pcmi_net() {
     (void)hipDeviceSynchronize();
     timed_clear();
+    pcmi::wgrad_group_destroy(wgroup);
     for (int i = 0; i < kSides; ++i) {
       if (side[i]) (void)hipStreamDestroy(side[i]);
       if (ev_main[i]) (void)hipEventDestroy(ev_main[i]);
@@ -467,6 +470,14 @@ struct BackwardRun {
     }
     return PCMI_OK;
   }
+  // The collected weight gradients go to the side stream now: everything their operands need has been enqueued on `st`.
+  int flush_group() {
+    if (wgrad_group_size(n.wgroup) == 0) return PCMI_OK;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
+    pending[0] = used[0] = true;
+    return wgrad_group_flush(n.wgroup, n.side[0]);
+  }
   int bucket_of(int64_t offp) const {
     int b = 0;
     for (int q = 0; q < n_buckets; ++q)
@@ -504,6 +515,8 @@ struct BackwardRun {
     }
     wst = n.side[0];
     wws = &n.ws_side[0];
+    if (!n.wgroup) n.wgroup = wgrad_group_create();
+    wgrad_group_drop(n.wgroup);
     if (const long us = debug_env_long("PCMI_DEBUG_SIDE_DELAY_US"); us > 0) {
       debug_delay_kernel<<<1, 1, 0, wst>>>((long long)us * 100);
       PCMI_LAUNCH_CHECK();
@@ -535,6 +548,18 @@ struct BackwardRun {
       // (weight gradients of the largest layers ON the chain instead of the side stream -- they cannot share a CU with the
       //  chain's kernels anyway, two of their workgroups fill register file and LDS -- were measured: 16.47 against 15.85 ms
       //  per step with the 175k-row layers in the chain, 17.1 with everything from 8000 rows: profiles/r04i_*)
+      // a coarse-level 3^3 layer: its gradient joins the open group and is launched with the others of its run (at the
+      // next layer that does not fit the group, at a bucket boundary, or at the end of the pass)
+      bool grouped = false;
+      if (!two_sides && !op.transpose && op.kernel_size == 3 && op.stride == 1 && !op.has_bias && map && n.timed_slot(i) < 0) {
+        grouped = wgrad_group_add(n.wgroup, x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, grads + op.w_off, 1, n.side[0]);
+        if (!grouped && wgrad_group_size(n.wgroup) > 0) {  // another tile shape, or the group is full: launch it, start a new one
+          rc = flush_group();
+          if (rc) return rc;
+          grouped = wgrad_group_add(n.wgroup, x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, grads + op.w_off, 1, n.side[0]);
+        }
+      }
+      if (!grouped) {
       const int sq = (two_sides && (std::min(n_in, n_out) < small_rows || op.kernel_size != 3 || op.stride != 1 ||
                                     std::min(op.cin, op.cout) < 64)) ? 1 : 0;
       wst = n.side[sq];
@@ -551,6 +576,7 @@ struct BackwardRun {
         PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tw + 5], wst));
         n.timed_hit[tw] |= 4;
       }
+      }  // !grouped
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
         const int tq = n.timed_slot(i);
@@ -590,6 +616,8 @@ struct BackwardRun {
     // callback (pcmi_net_stream_wait_bucket); the one join of the pass stays in end(), in front of the optimiser.
     for (int b = 0; b < n_buckets; ++b)
       if (bucket_last[b] == i && ready) {
+        rc = flush_group();  // (collected gradients may belong to this bucket: they must be on the side stream before its event)
+        if (rc) return rc;
         PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_main, st));
         for (int q = 0; q < pcmi_net::kSides; ++q) {
           if (used[q]) PCMI_HIP_CHECK(hipEventRecord(n.ev_bkt_side[q], n.side[q]));
@@ -603,7 +631,9 @@ struct BackwardRun {
 
   int end() {
     n.bkt_valid = false;
-    const int rc = join_side();
+    int rc = flush_group();
+    if (rc) return rc;
+    rc = join_side();
     if (rc) return rc;
     ps->valid = false;
     return PCMI_OK;

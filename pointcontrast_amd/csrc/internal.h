@@ -25,6 +25,18 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
                                int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
                                float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t spconv_workspace_m32(int64_t n_in, int64_t n_out, int cin, int cout, int K, int64_t M);
+// Weight gradients of several layers in ONE launch (spconv_wgrad.hip: wgrad_mfma_group_kernel).  add() == true: the layer's
+// gradient is enqueued by the next flush() on the stream given there (its operands must exist on that stream by then and
+// stay untouched until it); false: not a candidate, launch it with spconv_backward_weight.
+struct WgradGroupBuilder;
+WgradGroupBuilder* wgrad_group_create();
+void wgrad_group_destroy(WgradGroupBuilder* b);
+int wgrad_group_size(const WgradGroupBuilder* b);
+void wgrad_group_drop(WgradGroupBuilder* b);  // forget what was collected (a backward pass that failed half-way)
+bool wgrad_group_add(WgradGroupBuilder* b, const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                     int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, float* gweight, int accumulate,
+                     hipStream_t st);
+int wgrad_group_flush(WgradGroupBuilder* b, hipStream_t st);
 
 int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
                 int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,

@@ -48,6 +48,7 @@ struct WgradArgs {
   unsigned* counters;  // kArrive: one per (offset, tile-y, tile-z), zero on entry and on exit
 };
 enum { kSlabs = 0, kDirect = 1, kArrive = 2 };
+constexpr int kWgradGroupMax = 16;  // layers per grouped launch (WgradGroup travels in the kernel arguments: 16 x 128 B)
 
 template <int V>
 struct VecLoad;
@@ -185,18 +186,19 @@ __device__ inline void locate_chunk_wave(const int64_t* offs, int K, int64_t M, 
   }
 }
 
+// One workgroup of the pair-list kernel: chunk `bx` of the launch, channel tile (by, bz) of a (gy x gz) tiling.
+// (A function of its own since round 5: wgrad_mfma_group_kernel runs it for the workgroups of SEVERAL layers.)
 template <int CT, int NT, bool IDX, bool BUF>
-// min 2 waves/SIMD keeps the 9 accumulator tiles in VGPRs (198 registers); unbounded, hipcc used 190 + 144 AGPRs = 1 wave/SIMD
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_mfma_body(const WgradArgs& a, int bx, int by, int bz, int gy, int gz) {
   __shared__ float s_red[32 * CT][32 * NT + 1];
   __shared__ int64_t s_desc[6];
   __shared__ unsigned s_last;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int c0 = blockIdx.y * 32 * CT, n0 = blockIdx.z * 32 * NT;
+  const int c0 = by * 32 * CT, n0 = bz * 32 * NT;
   if (t == 0) {
-    locate_chunk(a.offs, a.mpk, a.M, a.chunk, blockIdx.x, s_desc);
-    s_desc[5] = blockIdx.x;  // slab of this chunk
+    locate_chunk(a.offs, a.mpk, a.M, a.chunk, bx, s_desc);
+    s_desc[5] = bx;  // slab of this chunk
   }
   __syncthreads();
   if (s_desc[0] < 0) return;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   if (a.mode != kArrive) return;
   // ---- the last workgroup of this (offset, tile) to arrive sums the slabs in chunk order -------------------------
   const int64_t first = s_desc[3], count = s_desc[4];
-  unsigned* counter = a.counters + ((int64_t)k_off * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z;
+  unsigned* counter = a.counters + ((int64_t)k_off * gy + by) * gz + bz;
   if (!arrive_last(counter, (unsigned)count, &s_last)) return;
   float sum[EPT];
 #pragma unroll
@@ -437,6 +439,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < EPT; ++j) dst[el[j]] = sum[j];
+}
+
+template <int CT, int NT, bool IDX, bool BUF>
+// min 2 waves/SIMD keeps the 9 accumulator tiles in VGPRs (198 registers); unbounded, hipcc used 190 + 144 AGPRs = 1 wave/SIMD
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
+  wgrad_mfma_body<CT, NT, IDX, BUF>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y, (int)gridDim.z);
+}
+
+// The weight gradients of SEVERAL layers in one launch (round 5).  The coarse levels of the U-Net (strides 8 and 16: 800-
+// 2700 rows per pair tensor, 128-256 channels) have 24 3^3 layers whose gradients are latency-, not matrix-bound: every
+// offset is one chunk ("direct" mode: the workgroup adds its tile straight into the flat gradient), a launch is 432
+// workgroups that each walk a few hundred pairs, and the 27 launches of a step took 62 us each on the weight-gradient
+// stream, one after the other (1.7 ms per step, 10-18 TFLOP/s).  All layers of a level are independent once their output
+// gradients exist, so the executor collects them (csrc/engine.hip) and launches one grid over all their workgroups:
+// workgroup b -> job (first[j] <= b), then the layer's own (chunk, tile) numbering.  Same workgroups, same arithmetic,
+// same sums as the single launches.  The jobs travel in the kernel arguments (no table upload): <= kWgradGroupMax.
+struct WgradGroup {
+  int n;
+  int first[kWgradGroupMax + 1];  // first[j]: first workgroup of job j; first[n]: grid size
+  WgradArgs job[kWgradGroupMax];
+};
+
+template <int CT, int NT>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_group_kernel(WgradGroup g) {
+  int j = 0;
+  for (int q = 1; q < g.n; ++q)
+    if ((int)blockIdx.x >= g.first[q]) j = q;  // (uniform)
+  const WgradArgs a = g.job[j];
+  const int local = (int)blockIdx.x - g.first[j];
+  const int gy = a.cin / (32 * CT), gz = a.cout / (32 * NT);
+  const int nchunks = a.K * a.mpk;  // maps only (a.offs != nullptr)
+  const int bx = local % nchunks, r = local / nchunks;
+  wgrad_mfma_body<CT, NT, true, true>(a, bx, r % gy, r / gy, gy, gz);
 }
 
 // gW[k][e] = sum over the chunks of offset k of slab[chunk][e] (fixed order -> deterministic).
@@ -695,31 +730,12 @@ size_t spconv_workspace_m32(int64_t n_in, int64_t n_out, int cin, int cout, int 
 }  // namespace pcmi
 
 namespace pcmi {
-int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
-                               int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
-                               float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-  PCMI_REQUIRE(in && gout && gweight && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_weight: bad argument");
+// Everything a pair-list launch needs besides the launch itself: operands, chunk size, chunk slots per offset, how the
+// chunks of an offset become gW (mode), the tile shape.  Shared by the single launch and the grouped one.
+static int wgrad_plan(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout, int64_t gout_ld, int64_t n_out,
+                      int cout, const pcmi_kmap_t* map, int transpose, float* gweight, int accumulate, int64_t M, hipStream_t st,
+                      WgradArgs* out, int* CT_out, int* NT_out, int64_t* nchunks_out) {
   const int K = map ? map->K : 1;
-  int64_t M;
-  if (map) {
-    const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
-    PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: rows do not match the map");
-    M = kmap_pairs_bound(*map);  // exact once the map's counts are on the host; only sizing / early-outs use it
-  } else {
-    PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: dense path needs n_in == n_out");
-    M = n_in;
-  }
-  const int64_t per_k = (int64_t)cin * cout;
-  if (M == 0) {
-    if (!accumulate) {
-      PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
-      if (gbias) PCMI_HIP_CHECK(hipMemsetAsync(gbias, 0, sizeof(float) * cout, st));
-    }
-    return PCMI_OK;
-  }
-  if (!transpose && !gbias && wgrad_x3t_eligible(map, n_in, n_out, cin, cout, in_ld, gout_ld) && in_ld % 4 == 0 &&
-      gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0)
-    return wgrad_x3t_run(in, in_ld, gout, gout_ld, n_out, cin, cout, map, gweight, accumulate, ws, ws_bytes, st);
   WgradArgs a;
   a.x = in;
   a.x_ld = in_ld;
@@ -762,6 +778,135 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   if (a.mode == kArrive) {
     a.counters = stream_counters(st, (size_t)K * (cin / (32 * CT)) * (cout / (32 * NT)));
     if (!a.counters) return PCMI_ERR_HIP;
+  }
+  *out = a;
+  *CT_out = CT;
+  *NT_out = NT;
+  *nchunks_out = nchunks;
+  return PCMI_OK;
+}
+
+// ---- grouped launches (wgrad_mfma_group_kernel) ------------------------------------------------------------------------
+// PCMI_WGRAD_GROUP=0: every layer its own launch (round 4's form; A/B).  Read per call.
+static bool wgrad_group_on() {
+  const char* e = getenv("PCMI_WGRAD_GROUP");
+  return !(e && e[0] == '0');
+}
+
+struct WgradGroupBuilder {
+  WgradGroup g;
+  int CT = 0, NT = 0;
+};
+
+WgradGroupBuilder* wgrad_group_create() {
+  WgradGroupBuilder* b = new WgradGroupBuilder();
+  b->g.n = 0;
+  b->g.first[0] = 0;
+  return b;
+}
+void wgrad_group_destroy(WgradGroupBuilder* b) { delete b; }
+int wgrad_group_size(const WgradGroupBuilder* b) { return b ? b->g.n : 0; }
+void wgrad_group_drop(WgradGroupBuilder* b) {
+  if (b) {
+    b->g.n = 0;
+    b->g.first[0] = 0;
+  }
+}
+
+// true: the layer's weight gradient will be enqueued by the next wgrad_group_flush (its operands must stay as they are
+// until then); false: not a candidate (the caller launches it by itself -- after flushing if the order matters to it).
+// Candidates: 3^3 / stride-1 table maps in "direct" mode (every offset one chunk: the coarse levels), accumulating,
+// 32-multiples of channels, 32-bit addressable operands, not taken by the split-precision tile kernel, and the tile
+// shape of the layers already collected.
+bool wgrad_group_add(WgradGroupBuilder* b, const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                     int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, float* gweight, int accumulate,
+                     hipStream_t st) {
+  if (!b || !wgrad_group_on() || !map || !in || !gout || !gweight || !accumulate) return false;
+  if (map->kernel_size != 3 || map->stride != 1 || map->K > PCMI_MAX_KERNEL_VOLUME || n_in != n_out || map->n_in != n_in) return false;
+  if (cin < 32 || cin % 32 != 0 || cout % 32 != 0 || in_ld % 4 != 0 || gout_ld % 4 != 0 || (uintptr_t)in % 16 != 0 ||
+      (uintptr_t)gout % 16 != 0)
+    return false;
+  if (n_in * in_ld * 4 > 0x7FFFFF00ll || n_out * gout_ld * 4 > 0x7FFFFF00ll) return false;
+  if (wgrad_x3t_eligible(map, n_in, n_out, cin, cout, in_ld, gout_ld)) return false;
+  const int64_t M = kmap_pairs_bound(*map);
+  if (M <= 0 || b->g.n >= kWgradGroupMax) return false;
+  WgradArgs a;
+  int CT = 1, NT = 1;
+  int64_t nchunks = 0;
+  if (wgrad_plan(in, in_ld, n_in, cin, gout, gout_ld, n_out, cout, map, 0, gweight, accumulate, M, st, &a, &CT, &NT, &nchunks) != PCMI_OK)
+    return false;
+  if (a.mode != kDirect || a.mpk != 1 || !a.idx_x) return false;
+  if (b->g.n > 0 && (CT != b->CT || NT != b->NT)) return false;
+  a.slabs = nullptr;
+  const int64_t wgs = nchunks * (cin / (32 * CT)) * (cout / (32 * NT));
+  if ((int64_t)b->g.first[b->g.n] + wgs > 0x3FFFFFFF) return false;
+  b->CT = CT;
+  b->NT = NT;
+  b->g.job[b->g.n] = a;
+  b->g.first[b->g.n + 1] = b->g.first[b->g.n] + (int)wgs;
+  ++b->g.n;
+  return true;
+}
+
+template <int CT>
+static int launch_group_nt(int NT, const WgradGroup& g, unsigned grid, hipStream_t st) {
+  switch (NT) {
+    case 1: wgrad_mfma_group_kernel<CT, 1><<<grid, 256, 0, st>>>(g); break;
+    case 2: wgrad_mfma_group_kernel<CT, 2><<<grid, 256, 0, st>>>(g); break;
+    case 3: wgrad_mfma_group_kernel<CT, 3><<<grid, 256, 0, st>>>(g); break;
+    default: set_error("wgrad group: bad NT %d", NT); return PCMI_ERR_INVALID;
+  }
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+int wgrad_group_flush(WgradGroupBuilder* b, hipStream_t st) {
+  if (!b || b->g.n == 0) return PCMI_OK;
+  const unsigned grid = (unsigned)b->g.first[b->g.n];
+  int rc;
+  switch (b->CT) {
+    case 1: rc = launch_group_nt<1>(b->NT, b->g, grid, st); break;
+    case 2: rc = launch_group_nt<2>(b->NT, b->g, grid, st); break;
+    default: rc = launch_group_nt<3>(b->NT, b->g, grid, st); break;
+  }
+  b->g.n = 0;
+  b->g.first[0] = 0;
+  return rc;
+}
+
+int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int cin, const float* gout,
+                               int64_t gout_ld, int64_t n_out, int cout, const pcmi_kmap_t* map, int transpose,
+                               float* gweight, float* gbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  PCMI_REQUIRE(in && gout && gweight && cin > 0 && cout > 0, PCMI_ERR_INVALID, "spconv_bwd_weight: bad argument");
+  const int K = map ? map->K : 1;
+  int64_t M;
+  if (map) {
+    const int64_t mi = transpose ? map->n_out : map->n_in, mo = transpose ? map->n_in : map->n_out;
+    PCMI_REQUIRE(mi == n_in && mo == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: rows do not match the map");
+    M = kmap_pairs_bound(*map);  // exact once the map's counts are on the host; only sizing / early-outs use it
+  } else {
+    PCMI_REQUIRE(n_in == n_out, PCMI_ERR_INVALID, "spconv_bwd_weight: dense path needs n_in == n_out");
+    M = n_in;
+  }
+  const int64_t per_k = (int64_t)cin * cout;
+  if (M == 0) {
+    if (!accumulate) {
+      PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));
+      if (gbias) PCMI_HIP_CHECK(hipMemsetAsync(gbias, 0, sizeof(float) * cout, st));
+    }
+    return PCMI_OK;
+  }
+  if (!transpose && !gbias && wgrad_x3t_eligible(map, n_in, n_out, cin, cout, in_ld, gout_ld) && in_ld % 4 == 0 &&
+      gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0)
+    return wgrad_x3t_run(in, in_ld, gout, gout_ld, n_out, cin, cout, map, gweight, accumulate, ws, ws_bytes, st);
+  WgradArgs a;
+  int CT = 1, NT = 1;
+  int64_t nchunks = 0;
+  const bool stem = cin < 8;
+  {
+    const int rc = wgrad_plan(in, in_ld, n_in, cin, gout, gout_ld, n_out, cout, map, transpose, gweight, accumulate, M, st, &a, &CT,
+                              &NT, &nchunks);
+    if (rc) return rc;
   }
   if (a.mode != kSlabs && map && !accumulate)  // an offset without pairs gets no workgroup: its slice must read zero
     PCMI_HIP_CHECK(hipMemsetAsync(gweight, 0, sizeof(float) * K * per_k, st));

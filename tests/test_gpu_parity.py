@@ -1394,6 +1394,35 @@ def test_engine_prepacked_weights_are_bit_identical(ME, monkeypatch):
   assert not torch.equal(res["1"][0][0], res["1"][1][0]), "the second iteration must see the updated weights"
 
 
+def test_grouped_weight_gradients_are_bit_identical(ME, monkeypatch):
+  """The executor collects the weight gradients of the coarse levels' 3^3 layers and launches them as ONE grid per run of
+  layers (spconv_wgrad.hip: wgrad_mfma_group_kernel; PCMI_WGRAD_GROUP=0: every layer its own launch): the same
+  workgroups doing the same arithmetic -> identical parameter gradients, with and without bucket boundaries cutting
+  the groups."""
+  from pointcontrast_amd.engine import NativeEngine
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.distributed import FlatParameters
+  cfg = get_config([])
+  _, dev = _make_models("Res16UNet34C", cfg, seed=5)
+  dev.train()
+  flat = FlatParameters(dev.parameters())
+  eng = NativeEngine(dev, flat)
+  b = synthetic.make_batch(seed=6, batch_size=2)
+  st = ME.SparseTensor(torch.from_numpy(b["sinput0_F"]), coords=torch.from_numpy(b["sinput0_C"])).to(DEV)
+  res = {}
+  for mode in ("1", "0"):
+    monkeypatch.setenv("PCMI_WGRAD_GROUP", mode)
+    f = eng.forward(0, st)
+    g = torch.randn(f.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    flat.zero_grad()
+    eng.backward(0, g)
+    torch.cuda.synchronize()
+    res[mode] = flat.g.clone()
+  assert float(res["1"].abs().max()) > 0
+  assert torch.equal(res["1"], res["0"]), "grouped != single launches: max |diff| %.3e" % float((res["1"] - res["0"]).abs().max())
+
+
 def test_engine_prepack_follows_each_pass_across_size_classes(ME, monkeypatch):
   """The slice width a layer's weights are packed for depends on its level's row count (classes at 512 / 2048 / 8192
   rows).  Batches whose levels fall into different classes, alternating between the two passes of an iteration, on a
