@@ -134,6 +134,7 @@ struct PassState {
     if (upd_host) (void)hipHostFree(upd_host);
     if (upd_dev) (void)hipFree(upd_dev);
     if (upd_copied) (void)hipEventDestroy(upd_copied);
+    if (x3_bwd_packed) (void)hipEventDestroy(x3_bwd_packed);
   }
   std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
   std::vector<size_t> stat_off;    // per op: BN save_mean/save_invstd (2*C floats) or L2 norms
@@ -158,6 +159,12 @@ struct PassState {
   bool x3_current = false;  // the last forward of this pass packed (the packs are those of its weights)
   int x3_n_jobs = 0;
   int64_t x3_items = 0;
+  // The jobs are ordered forward orientations first: [0, x3_items_fwd) is packed at the top of the forward pass, on its
+  // stream; the backward-data orientations [x3_items_fwd, x3_items) -- not needed before the backward pass -- are packed
+  // on the executor's side stream while the forward pass is in its coarse levels (PCMI_X3_PACK_SPLIT=0: all at the top).
+  int64_t x3_items_fwd = 0;
+  bool x3_bwd_pending = false;       // this pass's forward still owes the backward orientations
+  hipEvent_t x3_bwd_packed = nullptr;  // ... recorded behind them on the side stream: the backward pass waits for it
   // the job table goes up through pinned host memory with an asynchronous copy ON the pass's stream: ordered behind
   // the pack kernel of the previous table still queued there, and the enqueueing thread does not wait for the queue
   // to drain (a pageable hipMemcpy would).  Two host buffers: a rebuild waits only for the copy before the last.
@@ -277,10 +284,11 @@ static size_t op_workspace(const pcmi_net_op_t& op, int64_t n_in, int64_t n_out,
 // thread's convolution calls.  The job table is rebuilt when the parameter buffer changes or a level crosses a size
 // class (its slice width changes).  PCMI_X3_PREPACK=0: every convolution packs its own weights in front of its launch
 // (as the C-ABI entry points do).
-static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream_t st) {
+static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream_t st, bool split_bwd) {
   const char* pe = getenv("PCMI_X3_PREPACK");  // read per pass: the parity test runs both forms in one process
   const bool enabled = !(pe && pe[0] == '0');
   ps.x3_current = false;
+  ps.x3_bwd_pending = false;
   if (!enabled || !pcmi_spconv_split_precision()) {
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
@@ -301,12 +309,16 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
     std::vector<X3Prepacked> table;
     size_t bytes = 0;
     int64_t items = 0;
-    for (const auto& op : n.ops) {
-      if (op.type != PCMI_OP_CONV || op.kernel_size <= 1) continue;
-      const int K = op.kernel_size * op.kernel_size * op.kernel_size;
-      for (int tr = 0; tr < 2; ++tr) {  // 0: B = W[k] ([cin x cout]); 1: B = W[k]^T ([cout x cin])
+    int64_t items_fwd = 0;
+    for (int tr = 0; tr < 2; ++tr) {  // 0: B = W[k] ([cin x cout]); 1: B = W[k]^T ([cout x cin]) -- all forward jobs first
+      slot = 0;
+      if (tr == 1) items_fwd = items;
+      for (const auto& op : n.ops) {
+        if (op.type != PCMI_OP_CONV || op.kernel_size <= 1) continue;
+        const int K = op.kernel_size * op.kernel_size * op.kernel_size;
         const int C = tr ? op.cout : op.cin, N = tr ? op.cin : op.cout;
-        const int NT = nts[slot++];
+        const int NT = nts[slot + tr];
+        slot += 2;
         if (NT < 2) continue;
         X3PackJob j;
         j.w = params + op.w_off;
@@ -325,6 +337,7 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
         items += (int64_t)K * (C / 32) * N * 4;
       }
     }
+    ps.x3_items_fwd = items_fwd;
     if (!jobs.empty()) {
       // (a growing buffer drains the device first -- DevBuf::reserve -- so nothing in flight reads the old block)
       int rc = ps.x3_packs.reserve(bytes, st);
@@ -362,8 +375,11 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
   }
-  const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(ps.x3_jobs_dev.p), ps.x3_n_jobs, ps.x3_items, st);
+  // (training passes only owe the backward orientations; `split`: they follow later on the side stream, x3_pack_backward)
+  const int64_t upto = split_bwd ? ps.x3_items_fwd : ps.x3_items;
+  const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(ps.x3_jobs_dev.p), ps.x3_n_jobs, upto, st);
   if (rc) return rc;
+  ps.x3_bwd_pending = split_bwd && ps.x3_items > ps.x3_items_fwd;
   ps.x3_current = true;
   x3_set_prepacked(ps.x3_table.data(), (int)ps.x3_table.size());
   return PCMI_OK;
@@ -517,6 +533,10 @@ struct BackwardRun {
     wws = &n.ws_side[0];
     if (!n.wgroup) n.wgroup = wgrad_group_create();
     wgrad_group_drop(n.wgroup);
+    if (ps->x3_bwd_pending) {  // the backward-data weight packs of this pass were enqueued on the side stream (forward)
+      PCMI_HIP_CHECK(hipStreamWaitEvent(st, ps->x3_bwd_packed, 0));
+      ps->x3_bwd_pending = false;
+    }
     if (const long us = debug_env_long("PCMI_DEBUG_SIDE_DELAY_US"); us > 0) {
       debug_delay_kernel<<<1, 1, 0, wst>>>((long long)us * 100);
       PCMI_LAUNCH_CHECK();
@@ -870,9 +890,34 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   ps.coords = coords;
   // (the pack on a side stream, joined in front of the first convolution that needs it, was measured: 237.7 against
   //  238.3 pairs/s in line -- profiles/r03c_bench_ab.txt -- and is gone)
-  rc = x3_prepack(n, ps, params, st);
+  if (ps.x3_bwd_pending && ps.x3_bwd_packed) {
+    // a training forward of this pass that was never differentiated: its side-stream pack may still be reading the job
+    // table / writing the packs this pass is about to rebuild
+    PCMI_HIP_CHECK(hipStreamWaitEvent(st, ps.x3_bwd_packed, 0));
+    ps.x3_bwd_pending = false;
+  }
+  const bool train0 = (training & 1) != 0;
+  const bool pack_split = train0 && [] {  // PCMI_X3_PACK_SPLIT=0: both orientations at the top of the pass (round 4; A/B)
+    const char* e = getenv("PCMI_X3_PACK_SPLIT");
+    return !(e && e[0] == '0');
+  }();
+  rc = x3_prepack(n, ps, params, st, pack_split);
   const X3TableScope x3_scope;  // the table is this thread's only until the pass has been enqueued
   if (rc) return rc;
+  // where the backward-data orientations are packed: behind the first op of the third level (the pass is in its
+  // latency-bound coarse phase from there on and the side stream is idle during a forward pass) -- or behind the last op
+  int pack_bwd_at = -1;
+  if (ps.x3_bwd_pending) {
+    pack_bwd_at = n_ops - 1;
+    for (int i = 0; i < n_ops; ++i)
+      if (n.tensors[n.ops[i].out].level >= 2) {
+        pack_bwd_at = i;
+        break;
+      }
+    rc = ensure_streams(n, false);
+    if (rc) return rc;
+    if (!ps.x3_bwd_packed) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_bwd_packed, hipEventDisableTiming));
+  }
   g_prof_fwd.lap(2);
   // ---- run --------------------------------------------------------------------------------------
   if (!n.timed_ops.empty()) {  // the next event set of the ring (pcmi_net_time_ops); its old records are dropped
@@ -924,6 +969,13 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), stream);
     }
     if (rc) return rc;
+    if (i == pack_bwd_at) {  // the side stream starts behind this point of the pass (and behind the job table's upload)
+      PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
+      PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
+      rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(ps.x3_jobs_dev.p), ps.x3_n_jobs, ps.x3_items, n.side[0], ps.x3_items_fwd);
+      if (rc) return rc;
+      PCMI_HIP_CHECK(hipEventRecord(ps.x3_bwd_packed, n.side[0]));
+    }
     g_prof_fwd.lap(op.type == PCMI_OP_CONV ? 3 : (op.type == PCMI_OP_BN ? 4 : 5));
   }
   if ((defer || two_seg) && ps.upd_n > 0) {

@@ -60,7 +60,8 @@ struct X3PackJob {   // one (layer, orientation): B_k[c][n] = w[k * w_kstride + 
   void* out;           // x3_pack_bytes(K, C, N)
   int64_t first_item;  // exclusive prefix of K * (C / 32) * N * 4 over the jobs
 };
-int x3_pack_many(const X3PackJob* jobs_dev, int n_jobs, int64_t total_items, hipStream_t st);
+// packs the items [first_item, total_items) of the job list (a prefix / suffix of the jobs: the forward orientations first)
+int x3_pack_many(const X3PackJob* jobs_dev, int n_jobs, int64_t total_items, hipStream_t st, int64_t first_item = 0);
 struct X3Prepacked {
   const float* w;
   int transposed;  // 0: B = W[k] (forward), 1: B = W[k]^T (backward-data)

@@ -449,12 +449,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a) {
 
 // The weight gradients of SEVERAL layers in one launch (round 5).  The coarse levels of the U-Net (strides 8 and 16: 800-
 // 2700 rows per pair tensor, 128-256 channels) have 24 3^3 layers whose gradients are latency-, not matrix-bound: every
-// offset is one chunk ("direct" mode: the workgroup adds its tile straight into the flat gradient), a launch is 432
-// workgroups that each walk a few hundred pairs, and the 27 launches of a step took 62 us each on the weight-gradient
-// stream, one after the other (1.7 ms per step, 10-18 TFLOP/s).  All layers of a level are independent once their output
+// launch is a few hundred workgroups that each walk a few hundred pairs, and the 27 launches of a step took 62 us each on
+// the weight-gradient stream, one after the other (1.7 ms per step, 10-18 TFLOP/s).  All layers of a level are independent once their output
 // gradients exist, so the executor collects them (csrc/engine.hip) and launches one grid over all their workgroups:
-// workgroup b -> job (first[j] <= b), then the layer's own (chunk, tile) numbering.  Same workgroups, same arithmetic,
-// same sums as the single launches.  The jobs travel in the kernel arguments (no table upload): <= kWgradGroupMax.
+// workgroup b -> job (first[j] <= b), then the layer's own (offset, tile) numbering; every offset is ONE chunk ("direct"
+// mode: the workgroup adds its tile straight into the flat gradient), so the sums differ from the single launches' (which
+// cut long offsets into chunks) by their order only.  The jobs travel in the kernel arguments (no table upload): <= kWgradGroupMax.
 struct WgradGroup {
   int n;
   int first[kWgradGroupMax + 1];  // first[j]: first workgroup of job j; first[n]: grid size
@@ -835,7 +835,17 @@ bool wgrad_group_add(WgradGroupBuilder* b, const float* in, int64_t in_ld, int64
   int64_t nchunks = 0;
   if (wgrad_plan(in, in_ld, n_in, cin, gout, gout_ld, n_out, cout, map, 0, gweight, accumulate, M, st, &a, &CT, &NT, &nchunks) != PCMI_OK)
     return false;
-  if (a.mode != kDirect || a.mpk != 1 || !a.idx_x) return false;
+  if (!a.idx_x) return false;
+  // In a group every offset is ONE chunk (the workgroup adds its tile straight into the flat gradient: no slabs, no
+  // arrival counters): a single launch cuts a 2700-row offset into several chunks to get enough workgroups, a group has
+  // them from its other layers.  Up to 4096 pairs per offset (the longest chunk a single launch may take, wgrad_max_chunk).
+  const int64_t bound = wgrad_offset_bound(n_in, n_out);
+  if (bound > wgrad_max_chunk()) return false;
+  a.chunk = (int)align_up((size_t)bound, 128);
+  a.mpk = 1;
+  a.mode = kDirect;
+  a.counters = nullptr;
+  nchunks = a.K;
   if (b->g.n > 0 && (CT != b->CT || NT != b->NT)) return false;
   a.slabs = nullptr;
   const int64_t wgs = nchunks * (cin / (32 * CT)) * (cout / (32 * NT));

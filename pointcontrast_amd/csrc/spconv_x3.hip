@@ -82,8 +82,9 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const float* __restrict__ 
 // linear image, a wave instruction copies 1 KiB) instead of through 4 x BR staging registers per thread -- at NT = 3
 // that is what lets the kernel fit 3 waves per SIMD without spilling (185 -> 165 VGPRs).
 // The same for many (layer, orientation) jobs in one launch: a thread finds its job by bisection over the item prefix.
-__global__ __launch_bounds__(256) void x3_pack_many_kernel(const X3PackJob* __restrict__ jobs, int n_jobs, int64_t total) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void x3_pack_many_kernel(const X3PackJob* __restrict__ jobs, int n_jobs, int64_t total,
+                                                           int64_t item0) {
+  const int64_t idx = item0 + (int64_t)blockIdx.x * 256 + threadIdx.x;  // items [item0, total) of the job list
   if (idx >= total) return;
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {  // last job whose first item is <= idx
@@ -497,9 +498,9 @@ int x3_pack_weights(const ConvArgs& a, int NT, void* out, hipStream_t st) {
   return PCMI_OK;
 }
 
-int x3_pack_many(const X3PackJob* jobs_dev, int n_jobs, int64_t total_items, hipStream_t st) {
-  if (n_jobs <= 0 || total_items <= 0) return PCMI_OK;
-  x3_pack_many_kernel<<<dim3((unsigned)ceil_div(total_items, 256)), 256, 0, st>>>(jobs_dev, n_jobs, total_items);
+int x3_pack_many(const X3PackJob* jobs_dev, int n_jobs, int64_t total_items, hipStream_t st, int64_t first_item) {
+  if (n_jobs <= 0 || total_items <= first_item) return PCMI_OK;
+  x3_pack_many_kernel<<<dim3((unsigned)ceil_div(total_items - first_item, 256)), 256, 0, st>>>(jobs_dev, n_jobs, total_items, first_item);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 5, call 6: grouped coarse-level weight gradients (PCMI_WGRAD_GROUP) -- bit-identity + network tests, step A/B,
-# kernel statistics; small-BN thresholds (1536 forward / 768 backward) against 768 / 768.
+# Round 5, call 7: grouped coarse-level weight gradients (one chunk per offset) and the weight pack split by orientation
+# (backward orientations on the side stream during the forward pass): tests, step A/B, kernel statistics.
 set -u
 ulimit -c 0
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$ROOT"
 export TMPDIR=/tmp
-TAG=${TAG:-r05f}
+TAG=${TAG:-r05g}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
 T0=$(date +%s)
@@ -32,14 +32,16 @@ run() {  # label n env...
   done
 }
 stamp "1 tests"
-timeout 900 python -m pytest "tests/test_gpu_parity.py::test_grouped_weight_gradients_match_single_launches" "tests/test_gpu_parity.py::test_network_features_loss_and_grads" \
-  "tests/test_gpu_parity.py::test_batchnorm_parity" tests/test_gpu_bucket_sync.py tests/test_gpu_fullsize.py -m gpu -q --tb=short -p no:cacheprovider > $O/pytest_sel.log 2>&1
-echo "pytest(sel) exit $?" | tee -a $O/stages.log; grep -E "passed|failed|skipped" $O/pytest_sel.log | tail -3; grep -E "^FAILED|^ERROR" $O/pytest_sel.log | head -20
+timeout 900 python -m pytest "tests/test_gpu_parity.py::test_grouped_weight_gradients_match_single_launches" "tests/test_gpu_parity.py::test_engine_prepacked_weights_are_bit_identical" \
+  "tests/test_gpu_parity.py::test_engine_prepack_follows_each_pass_across_size_classes" "tests/test_gpu_parity.py::test_network_features_loss_and_grads" \
+  tests/test_gpu_bucket_sync.py tests/test_gpu_trace.py "tests/test_gpu_fullsize.py::test_full_config_gradients_match_oracle" "tests/test_gpu_fullsize.py::test_full_config_step_is_bit_reproducible" \
+  -m gpu -q --tb=short -p no:cacheprovider -s > $O/pytest_sel.log 2>&1
+echo "pytest(sel) exit $?" | tee -a $O/stages.log; grep -E "passed|failed|skipped" $O/pytest_sel.log | tail -3; grep -E "^FAILED|^ERROR|worst tensor" $O/pytest_sel.log | head -20
 stamp "2 A/B"
-run group_off 3 PCMI_WGRAD_GROUP=0
-run group_on 3 PCMI_NOP=1
-run bn_768_768 3 PCMI_BN_SMALL_ROWS=768
-run group_on_b 2 PCMI_NOP=1
+run base_off 3 PCMI_WGRAD_GROUP=0 PCMI_X3_PACK_SPLIT=0
+run group_only 3 PCMI_X3_PACK_SPLIT=0
+run split_only 3 PCMI_WGRAD_GROUP=0
+run both 3 PCMI_NOP=1
 stamp "3 rocprofv3 kernel stats"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o bench -- \
     python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > "$O/prof.log" 2>&1 )
@@ -47,5 +49,5 @@ echo "prof exit $?" >> $O/stages.log
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O/prof -name "*kernel_trace.csv" -exec cp {} $O/kernel_trace.csv \;
 rm -rf $O/prof
-grep -E "wgrad" $O/kernel_stats.csv | cut -c1-150
+grep -E "wgrad|x3_pack" $O/kernel_stats.csv | cut -c1-150
 stamp "done"
