@@ -471,6 +471,8 @@ struct BackwardRun {
   DevBuf* wws = nullptr;
   bool pending[pcmi_net::kSides] = {false, false}, used[pcmi_net::kSides] = {false, false};
   float* scratch_g = nullptr;
+  size_t scratch_stride = 0;
+  int bn_seen = 0;
   std::vector<int> bucket_last;
 
   BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
@@ -517,9 +519,15 @@ struct BackwardRun {
     }
     int rc = ps->grad.reserve(off, st);
     if (rc) return rc;
-    rc = ps->small.reserve((size_t)4 * max_c * sizeof(float) + 256, st);  // per segment: dbeta, dgamma
+    // per BatchNorm op its own [2 segments][dbeta, dgamma] sums: a BatchNorm whose parameter gradients are accumulated on
+    // the side stream (bn_param_accumulate) must not have its sums overwritten by the next BatchNorm of the chain
+    int n_bn = 0;
+    for (int i = 0; i < n_ops; ++i) n_bn += n.ops[i].type == PCMI_OP_BN;
+    rc = ps->small.reserve((size_t)(n_bn + 1) * 4 * max_c * sizeof(float) + 256, st);
     if (rc) return rc;
     scratch_g = (float*)ps->small.p;
+    scratch_stride = 4 * (size_t)max_c;
+    bn_seen = 0;
     two_sides = debug_env_long("PCMI_WGRAD_SIDE2") != 0;
     rc = ensure_streams(n, two_sides);
     if (rc) return rc;
@@ -614,11 +622,19 @@ struct BackwardRun {
       if (op.in2 >= 0) dr = grad_view(n, *ps, op.in2, d_out, d_ld);
       const float* stats0 = (const float*)(ps->act.p + ps->stat_off[i]);
       const int64_t sp = ps->split[n.tensors[op.in].level];
-      if (sp < n_in)  // a segment = one forward call of the reference: own statistics, own sums; one launch pair
+      if (sp < n_in) {  // a segment = one forward call of the reference: own statistics, own sums; one launch pair
+        float* sums = scratch_g + (size_t)(++bn_seen) * scratch_stride;
+        int deferred = 0;
         rc = bn_backward2(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, sp, op.cout, params + op.w_off, stats0,
-                          stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, grads + op.w_off,
-                          grads + op.b_off, ps->ws.p, ps->ws.cap, st);
-      else
+                          stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, sums, grads + op.w_off,
+                          grads + op.b_off, ps->ws.p, ps->ws.cap, st, two_sides ? nullptr : &deferred);
+        if (!rc && deferred) {  // the parameter gradients of this BatchNorm: on the side stream, behind the sums
+          PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
+          PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
+          pending[0] = used[0] = true;
+          rc = bn_param_accumulate(sums, op.cout, grads + op.w_off, grads + op.b_off, n.side[0]);
+        }
+      } else
         rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats0,
                          stats0 + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, scratch_g + op.cout,
                          grads + op.w_off, grads + op.b_off, ps->ws.p, ps->ws.cap, st);

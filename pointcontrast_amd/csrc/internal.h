@@ -64,7 +64,10 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
 int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld, int64_t n,
                  int64_t split, int c, const float* gamma, const float* save_mean, const float* save_invstd, int stat_stride,
                  float* dx, int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* sums, float* acc_dgamma,
-                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
+                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, int* deferred_acc = nullptr);
+// deferred_acc != nullptr: the call MAY leave the parameter-gradient accumulation to the caller (*deferred_acc = 1):
+// bn_param_accumulate(sums, ...) on a stream ordered behind the call, with `sums` untouched until then
+int bn_param_accumulate(const float* sums, int c, float* acc_dgamma, float* acc_dbeta, hipStream_t st);
 int bn_running_update(const BnRunningUpdate* table_dev, int n_entries, hipStream_t st);
 
 // coords.hip: a cached map as it is -- M == -1 / offs_host unset when pcmi_coords_plan_unet built it and nobody has asked

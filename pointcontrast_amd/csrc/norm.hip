@@ -687,6 +687,8 @@ struct BnSmallBwd {
 // The segments of a two-segment tensor are handled ONE AFTER THE OTHER by the same workgroup: the parameter gradients
 // are (acc + sums of segment 0) + sums of segment 1, in that order -- what two consecutive one-segment calls accumulate
 // (and what bn_bwd_apply_kernel does) -- without a hand-over between workgroups.
+// gridDim.y == 2 (a two-segment tensor whose parameter gradients somebody else accumulates from `sum_g / sum_gx` --
+// a.acc_g == nullptr, bn_param_acc_kernel): one workgroup per segment, side by side.
 template <int RPT, int THREADS>
 __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
   __shared__ float4 s_w[16][kSmallCG];
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
   const int col4 = blockIdx.x * kSmallCG + cg;
   const int cb = blockIdx.x * (4 * kSmallCG);
   const int n_seg = a.split < a.n ? 2 : 1;
+  const int sg_first = gridDim.y > 1 ? (int)blockIdx.y : 0, sg_end = gridDim.y > 1 ? (int)blockIdx.y + 1 : n_seg;
   const float4 ga = reinterpret_cast<const float4*>(a.gamma)[col4];
   float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
   if (a.acc_g && rl == 0) {
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
   const uint32_t lane_b = (uint32_t)cg * 16u;
   const bool masked = a.ymask != nullptr, has_res = a.dres != nullptr;
 #pragma unroll 1
-  for (int sg = 0; sg < n_seg; ++sg) {
+  for (int sg = sg_first; sg < sg_end; ++sg) {
     const int64_t base = sg ? a.split : 0;
     const int ns = (int)(n_seg > 1 ? (sg ? a.n - a.split : a.split) : a.n);
     const float4 mu = reinterpret_cast<const float4*>(a.mean + sg * a.stat_stride)[col4];
@@ -771,6 +774,23 @@ __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
     reinterpret_cast<float4*>(a.acc_g)[col4] = pa;
     reinterpret_cast<float4*>(a.acc_gx)[col4] = pb;
   }
+}
+
+// acc += sums of segment 0, then += sums of segment 1 (the order of two consecutive one-segment calls): the parameter
+// gradients of a BatchNorm whose backward ran its two segments side by side.  One thread per four channels.
+__global__ void bn_param_acc_kernel(float* __restrict__ acc_g, float* __restrict__ acc_gx, const float* __restrict__ sum_g,
+                                    const float* __restrict__ sum_gx, int sum_stride, int c4, int n_seg) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= c4) return;
+  float4 a = reinterpret_cast<float4*>(acc_g)[t], b = reinterpret_cast<float4*>(acc_gx)[t];
+  for (int sg = 0; sg < n_seg; ++sg) {
+    const float4 u = reinterpret_cast<const float4*>(sum_g + sg * sum_stride)[t];
+    const float4 v = reinterpret_cast<const float4*>(sum_gx + sg * sum_stride)[t];
+    a = make_float4(a.x + u.x, a.y + u.y, a.z + u.z, a.w + u.w);
+    b = make_float4(b.x + v.x, b.y + v.y, b.z + v.z, b.w + v.w);
+  }
+  reinterpret_cast<float4*>(acc_g)[t] = a;
+  reinterpret_cast<float4*>(acc_gx)[t] = b;
 }
 
 // y = relu?( (x - mean) * (invstd * gamma) + beta (+ residual) )
@@ -988,10 +1008,10 @@ static int bn_small_forward(const float* x, int64_t x_ld, int64_t n, int64_t spl
   return PCMI_OK;
 }
 
-static int bn_small_backward(const BnSmallBwd& a, int c, hipStream_t st) {
+static int bn_small_backward(const BnSmallBwd& a, int c, hipStream_t st, bool parallel_segments = false) {
   const bool two = a.split < a.n;
   const int64_t longest = two ? std::max(a.split, a.n - a.split) : a.n;
-  const dim3 grid((unsigned)(c / (4 * kSmallCG)));
+  const dim3 grid((unsigned)(c / (4 * kSmallCG)), (two && parallel_segments) ? 2u : 1u);
   PCMI_BN_SMALL_DISPATCH(bn_small_bwd_kernel, a, grid, longest, st);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
@@ -1148,7 +1168,7 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
 int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld, int64_t n,
                  int64_t split, int c, const float* gamma, const float* save_mean, const float* save_invstd, int stat_stride,
                  float* dx, int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* sums, float* acc_dgamma,
-                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st) {
+                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, int* deferred_acc) {
   int rc = check_rows("bn_bwd2(dy)", dy, dy_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_bwd2(x)", x, x_ld, c);
@@ -1169,13 +1189,20 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
   float* part = (float*)ws;
   RedFinal fin;
   memset(&fin, 0, sizeof(fin));
-  if (bn_small_eligible(longest, c, true)) {
+  // deferred_acc (nullable): the caller can add the two segments' sums to the parameter gradients itself
+  // (bn_param_accumulate, on any stream ordered behind this call) -- then the segments run side by side, and the one-launch
+  // form pays up to the forward threshold; else one workgroup walks them in order and accumulates.
+  if (deferred_acc) *deferred_acc = 0;
+  if (bn_small_eligible(longest, c, deferred_acc == nullptr)) {
     BnSmallBwd a;
     a.dy = dy; a.dy_ld = dy_ld; a.x = x; a.x_ld = x_ld; a.ymask = relu_mask_y; a.y_ld = y_ld; a.n = n; a.split = split;
     a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd; a.stat_stride = stat_stride;
     a.dx = dx; a.dx_ld = dx_ld; a.dres = dres; a.dres_ld = dres_ld; a.dres_accumulate = dres_accumulate;
-    a.sum_g = sums; a.sum_gx = sums + c; a.sum_stride = 2 * c; a.acc_g = acc_dbeta; a.acc_gx = acc_dgamma;
-    return bn_small_backward(a, c, st);
+    a.sum_g = sums; a.sum_gx = sums + c; a.sum_stride = 2 * c;
+    a.acc_g = deferred_acc ? nullptr : acc_dbeta;
+    a.acc_gx = deferred_acc ? nullptr : acc_dgamma;
+    if (deferred_acc) *deferred_acc = 1;
+    return bn_small_backward(a, c, st, deferred_acc != nullptr);
   }
   const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
   const bool fuse = fuse_final_enabled() && !lean;  // (the lean statistics kernel never merges: it has no registers for it)
@@ -1212,6 +1239,14 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
                                                             save_invstd, sums, sums + c, dx, dx_ld, dres, dres_ld,
                                                             dres_accumulate, split, stat_stride / 4, 2 * c / 4, acc_dbeta,
                                                             acc_dgamma);
+  PCMI_LAUNCH_CHECK();
+  return PCMI_OK;
+}
+
+// (acc_dbeta, acc_dgamma) += the sums bn_backward2 left in `sums` ([2][2c]: dbeta, dgamma per segment) with *deferred_acc == 1
+int bn_param_accumulate(const float* sums, int c, float* acc_dgamma, float* acc_dbeta, hipStream_t st) {
+  PCMI_REQUIRE(sums && acc_dgamma && acc_dbeta && c % 4 == 0, PCMI_ERR_INVALID, "bn_param_accumulate: bad argument");
+  bn_param_acc_kernel<<<(unsigned)ceil_div(c / 4, 64), 64, 0, st>>>(acc_dbeta, acc_dgamma, sums, sums + c, 2 * c, c / 4, 2);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
