@@ -473,6 +473,7 @@ struct BackwardRun {
   float* scratch_g = nullptr;
   size_t scratch_stride = 0;
   int bn_seen = 0;
+  bool bn_par = true;
   std::vector<int> bucket_last;
 
   BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
@@ -528,6 +529,10 @@ struct BackwardRun {
     scratch_g = (float*)ps->small.p;
     scratch_stride = 4 * (size_t)max_c;
     bn_seen = 0;
+    {  // PCMI_BN_SMALL_PAR=0: a small BatchNorm's segments one after the other, parameter gradients in the kernel (A/B)
+      const char* e = getenv("PCMI_BN_SMALL_PAR");
+      bn_par = !(e && e[0] == '0');
+    }
     two_sides = debug_env_long("PCMI_WGRAD_SIDE2") != 0;
     rc = ensure_streams(n, two_sides);
     if (rc) return rc;
@@ -627,7 +632,7 @@ struct BackwardRun {
         int deferred = 0;
         rc = bn_backward2(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, sp, op.cout, params + op.w_off, stats0,
                           stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, sums, grads + op.w_off,
-                          grads + op.b_off, ps->ws.p, ps->ws.cap, st, two_sides ? nullptr : &deferred);
+                          grads + op.b_off, ps->ws.p, ps->ws.cap, st, (two_sides || !bn_par) ? nullptr : &deferred);
         if (!rc && deferred) {  // the parameter gradients of this BatchNorm: on the side stream, behind the sums
           PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
           PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));

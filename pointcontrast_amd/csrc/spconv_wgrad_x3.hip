@@ -544,10 +544,6 @@ static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz, int per_cu = 2) {
   // producer / consumer form is one 8-wave workgroup per CU); one round of them, at least 4 tiles per workgroup, a
   // multiple of 8 row blocks
   int64_t rb = (int64_t)per_cu * num_cu() / ((int64_t)NG * gy * gz);
-  if (per_cu == 1) {  // PCMI_WGRAD_X3P_RB: row blocks of the producer / consumer form (x 7 offset groups = workgroups = CUs; A/B)
-    const char* e = getenv("PCMI_WGRAD_X3P_RB");
-    if (e && atoi(e) >= 8) rb = atoi(e) / (gy * gz);
-  }
   rb = std::min<int64_t>(rb, n_tiles / 4);
   rb = std::max<int64_t>(8, std::min<int64_t>(kWgradTMaxRB, rb / 8 * 8));
   return (int)rb;
