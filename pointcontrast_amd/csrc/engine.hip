@@ -473,7 +473,7 @@ struct BackwardRun {
   float* scratch_g = nullptr;
   size_t scratch_stride = 0;
   int bn_seen = 0;
-  bool bn_par = true;
+  bool bn_par = false;
   std::vector<int> bucket_last;
 
   BackwardRun(pcmi_net& net, const BackwardJob& j, const float* prm, float* g, const int64_t* blo, int nb, pcmi_ready_fn r,
@@ -529,9 +529,12 @@ struct BackwardRun {
     scratch_g = (float*)ps->small.p;
     scratch_stride = 4 * (size_t)max_c;
     bn_seen = 0;
-    {  // PCMI_BN_SMALL_PAR=0: a small BatchNorm's segments one after the other, parameter gradients in the kernel (A/B)
+    {  // PCMI_BN_SMALL_PAR=1: a small BatchNorm's backward with its two segments side by side and the parameter gradients
+       // added by a kernel on the side stream.  Measured (profiles/r05h_*): 272.5 against 275.9 pairs/s with the segments one
+       // after the other inside the kernel -- 30 more launches and event pairs on the weight-gradient stream cost more than
+       // the shorter BatchNorm kernels return.  Off.
       const char* e = getenv("PCMI_BN_SMALL_PAR");
-      bn_par = !(e && e[0] == '0');
+      bn_par = e && e[0] == '1';
     }
     two_sides = debug_env_long("PCMI_WGRAD_SIDE2") != 0;
     rc = ensure_streams(n, two_sides);
