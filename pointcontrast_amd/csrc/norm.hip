@@ -1012,7 +1012,16 @@ static int bn_small_backward(const BnSmallBwd& a, int c, hipStream_t st, bool pa
   const bool two = a.split < a.n;
   const int64_t longest = two ? std::max(a.split, a.n - a.split) : a.n;
   const dim3 grid((unsigned)(c / (4 * kSmallCG)), (two && parallel_segments) ? 2u : 1u);
-  PCMI_BN_SMALL_DISPATCH(bn_small_bwd_kernel, a, grid, longest, st);
+  if (longest > 64 * kSmallMaxRPT) {
+    // Above 768 rows: 256 row lanes (1024 threads, <= 128 registers) x <= 6 rows.  The 128-lane x 12-row form the forward
+    // kernel uses there needs 226-248 registers in the backward kernel (two resident tensors per row + the mask) and took
+    // 30 us per launch at 1350 rows (profiles/r05e_*, r05h_*).
+    const int need = (int)ceil_div(longest, 256);
+    if (need <= 4) bn_small_bwd_kernel<4, 1024><<<grid, 1024, 0, st>>>(a);
+    else bn_small_bwd_kernel<6, 1024><<<grid, 1024, 0, st>>>(a);
+  } else {
+    PCMI_BN_SMALL_DISPATCH(bn_small_bwd_kernel, a, grid, longest, st);
+  }
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
