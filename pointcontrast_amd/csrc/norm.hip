@@ -969,7 +969,9 @@ static bool bn_lean_eligible(int64_t n, int c, int64_t x_ld, int64_t dy_ld, int6
 // rows.  Defaults 1536 forward, 768 backward -- measured on the bench batch (profiles/r05e_*): the forward kernel takes
 // 6.1 us at 403 rows per segment and 9.3 us at 1350 (three launches: ~19 us + two gaps); the backward kernel, which
 // walks the two segments of a pair one after the other (the parameter gradients are (acc + segment 0) + segment 1),
-// 12.6 us at 403 rows but 32.6 us at 1350 -- slower than the three launches it replaces (~24 us).
+// 12.6 us at 403 rows but 32.6 us at 1350 -- slower than the three launches it replaces (~24 us).  Two more forms of
+// the backward kernel at 1350 rows lost as well: the segments side by side with the parameter gradients added on the
+// side stream (-1.2 % of the step, r05h_*), and 256 row lanes x 6 rows in 128 registers (-2.2 %, r05i_*).
 static int64_t bn_small_rows(bool backward) {
   const char* e = getenv(backward ? "PCMI_BN_SMALL_BWD_ROWS" : "PCMI_BN_SMALL_ROWS");
   const int64_t v = e ? (int64_t)atoll(e) : (int64_t)(backward ? 768 : 1536);
@@ -1012,16 +1014,7 @@ static int bn_small_backward(const BnSmallBwd& a, int c, hipStream_t st, bool pa
   const bool two = a.split < a.n;
   const int64_t longest = two ? std::max(a.split, a.n - a.split) : a.n;
   const dim3 grid((unsigned)(c / (4 * kSmallCG)), (two && parallel_segments) ? 2u : 1u);
-  if (longest > 64 * kSmallMaxRPT) {
-    // Above 768 rows: 256 row lanes (1024 threads, <= 128 registers) x <= 6 rows.  The 128-lane x 12-row form the forward
-    // kernel uses there needs 226-248 registers in the backward kernel (two resident tensors per row + the mask) and took
-    // 30 us per launch at 1350 rows (profiles/r05e_*, r05h_*).
-    const int need = (int)ceil_div(longest, 256);
-    if (need <= 4) bn_small_bwd_kernel<4, 1024><<<grid, 1024, 0, st>>>(a);
-    else bn_small_bwd_kernel<6, 1024><<<grid, 1024, 0, st>>>(a);
-  } else {
-    PCMI_BN_SMALL_DISPATCH(bn_small_bwd_kernel, a, grid, longest, st);
-  }
+  PCMI_BN_SMALL_DISPATCH(bn_small_bwd_kernel, a, grid, longest, st);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

@@ -710,7 +710,9 @@ size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, in
   const int lo = wgrad_lo_chunk(n_in, n_out, K, M);
   const int64_t nchunks = K > 1 ? (int64_t)K * ceil_div(wgrad_offset_bound(n_in, n_out), lo) : ceil_div(M, lo);
   const size_t pairwise = (size_t)std::max<int64_t>(nchunks, 1) * cin * cout * sizeof(float);
-  const size_t tiled = (K == 27 && n_in == n_out) ? wgrad_x3t_workspace(n_out, cin, cout) : 0;  // spconv_wgrad_x3.hip
+  // spconv_wgrad_x3.hip (K = 1: the dense 1x1 form of the same kernel, up to 128 row blocks of one slab each)
+  const size_t tiled = (K == 27 && n_in == n_out) ? wgrad_x3t_workspace(n_out, cin, cout)
+                                                  : ((K == 1 && n_in == n_out) ? (size_t)128 * cin * cout * sizeof(float) : 0);
   return std::max(pairwise, tiled) + (size_t)1024 * cout * sizeof(float);
 }
 

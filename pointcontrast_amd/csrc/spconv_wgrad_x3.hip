@@ -35,7 +35,7 @@ struct WgradTArgs {
   int64_t x_ld;
   const float* g;       // [*, g_ld] gradient of the convolution output
   int64_t g_ld;
-  const int32_t* nbr;   // [K][n_rows] neighbour table in processing order (nbr_perm when perm is set)
+  const int32_t* nbr;   // [K][n_rows] neighbour table in processing order (nbr_perm when perm is set); nullptr: identity (K = 1)
   const int32_t* perm;  // nullable: position -> output row
   int64_t n_rows;
   int K, C, N;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3t_kernel(WgradTArgs a) {
       const int s = idx >> 6, rr = idx & 63, k = kbase + s;
       const int64_t pos = p0 + rr;
       int32_t v = -1;
-      if (k < a.K && pos < a.n_rows) v = a.nbr[(int64_t)k * a.n_rows + pos];
+      if (k < a.K && pos < a.n_rows) v = a.nbr ? a.nbr[(int64_t)k * a.n_rows + pos] : (int32_t)pos;  // (nullptr: the 1x1 convolution)
       s_xoff[s][rr] = v >= 0 ? (uint32_t)v * xld : kAbsent;
       const bool any = __ballot(v >= 0) != 0ull;
       if (lane == 0) s_any[s] = any ? 1 : 0;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
       for (int j = 0; j < (KG + 3) / 4; ++j) {
         const int sx = wave - 4 + 4 * j, k = kbase + sx;
         tab_v[j] = -1;
-        if (sx < KG && in_range && k < a.K && pos < a.n_rows) tab_v[j] = a.nbr[(int64_t)k * a.n_rows + pos];
+        if (sx < KG && in_range && k < a.K && pos < a.n_rows) tab_v[j] = a.nbr ? a.nbr[(int64_t)k * a.n_rows + pos] : (int32_t)pos;
       }
       // (unconditional reset + ONE guarded load: a reset inside `if (wave == 4)` becomes a select on the register's old
       //  value -- the result of the load two tiles ago as far as the compiler knows -- and with it an s_waitcnt vmcnt(0))
@@ -525,9 +525,18 @@ static int64_t wgrad_x3t_min_rows() {
   return e ? (int64_t)atoll(e) : (int64_t)8192;
 }
 
+// PCMI_WGRAD_X3T_DENSE=0: the 1x1 convolutions (no map: K = 1, identity table) stay on the pair-list kernel (A/B)
+static bool wgrad_x3t_dense_on() {
+  const char* e = getenv("PCMI_WGRAD_X3T_DENSE");
+  return !(e && e[0] == '0');
+}
+
+// map == nullptr: a 1x1 convolution, gW = X^T G over all rows -- the same kernel with K = 1 and the identity table
+// (round 5: the level-1 128 -> 96 downsample gradient took 350 us in the step on the fp32 pair-list kernel, 12 TFLOP/s).
 bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int cin, int cout, int64_t in_ld, int64_t gout_ld) {
   const int64_t mr = wgrad_x3t_min_rows();
-  return map && map->kernel_size == 3 && map->stride == 1 && mr > 0 && n_out >= mr && n_in == n_out && cin >= 64 && cout >= 64 &&
+  const bool shape = map ? (map->kernel_size == 3 && map->stride == 1) : wgrad_x3t_dense_on();
+  return shape && mr > 0 && n_out >= mr && n_in == n_out && cin >= 64 && cout >= 64 &&
          wgrad_x3t_tw(cin) > 0 && wgrad_x3t_tw(cout) > 0 && n_in * in_ld * 4 <= 0x7FFFFF00ll && n_out * gout_ld * 4 <= 0x7FFFFF00ll;
 }
 
@@ -537,8 +546,8 @@ static bool wgrad_x3p_on() {
   return e ? atoi(e) != 0 : true;
 }
 
-static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz, int per_cu = 2) {
-  const int NG = (PCMI_MAX_KERNEL_VOLUME + kWgradTKG - 1) / kWgradTKG;
+static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz, int per_cu = 2, int K = PCMI_MAX_KERNEL_VOLUME) {
+  const int NG = (K + kWgradTKG - 1) / kWgradTKG;
   const int64_t n_tiles = ceil_div(n_rows, 64);
   // `per_cu` resident workgroups per CU (wgrad_x3t_kernel: two -- one per CU: 238.6 against 240 pairs/s in the step; the
   // producer / consumer form is one 8-wave workgroup per CU); one round of them, at least 4 tiles per workgroup, a
@@ -565,28 +574,29 @@ static void launch_x3t(const WgradTArgs& a, dim3 grid, bool pc, hipStream_t st) 
 int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gout_ld, int64_t n_rows, int cin, int cout,
                   const pcmi_kmap_t* map, float* gweight, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   const int MTW = wgrad_x3t_tw(cin), NTW = wgrad_x3t_tw(cout);
-  PCMI_REQUIRE(MTW > 0 && NTW > 0 && map && map->K <= PCMI_MAX_KERNEL_VOLUME, PCMI_ERR_UNSUPPORTED, "wgrad x3t: channels (%d, %d)", cin, cout);
+  PCMI_REQUIRE(MTW > 0 && NTW > 0 && (!map || map->K <= PCMI_MAX_KERNEL_VOLUME), PCMI_ERR_UNSUPPORTED, "wgrad x3t: channels (%d, %d)", cin, cout);
   WgradTArgs a;
   a.x = in;
   a.x_ld = in_ld;
   a.g = gout;
   a.g_ld = gout_ld;
-  a.nbr = (map->perm && map->nbr_perm) ? map->nbr_perm : map->nbr;
-  a.perm = (map->perm && map->nbr_perm) ? map->perm : nullptr;
+  a.nbr = !map ? nullptr : ((map->perm && map->nbr_perm) ? map->nbr_perm : map->nbr);
+  a.perm = (map && map->perm && map->nbr_perm) ? map->perm : nullptr;
   a.n_rows = n_rows;
-  a.K = map->K;
+  const int K = map ? map->K : 1;
+  a.K = K;
   a.C = cin;
   a.N = cout;
   const int gy = cin / (32 * MTW), gz = cout / (32 * NTW);
-  a.NG = (map->K + kWgradTKG - 1) / kWgradTKG;
+  a.NG = (K + kWgradTKG - 1) / kWgradTKG;
   const bool pc = wgrad_x3p_on();
-  a.RB = wgrad_x3t_rb(n_rows, gy, gz, pc ? 1 : 2);
+  a.RB = wgrad_x3t_rb(n_rows, gy, gz, pc ? 1 : 2, K);
   // (the producer / consumer form takes 8 x NG x (RB / 8) = 224 of the 256 CUs at NG = 7: with every CU used -- 36 row
   //  blocks, 252 workgroups -- it is 11 % faster alone (0.501 against 0.560 ms) and SLOWER in the step (253.1-254.6 against
   //  256.6-256.9 pairs/s): the CUs it leaves are where the backward chain's kernels run meanwhile; fewer row blocks lose
   //  again -- 24: 254.6, 16: 252.7.  profiles/r04jk_wgrad_producer_consumer.txt)
   a.tiles_per_rb = (int)ceil_div(ceil_div(n_rows, 64), a.RB);
-  const size_t need = (size_t)map->K * a.RB * cin * cout * sizeof(float);
+  const size_t need = (size_t)K * a.RB * cin * cout * sizeof(float);
   PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "wgrad x3t: workspace %zu < %zu bytes", ws_bytes, need);
   a.slabs = (float*)ws;
   const dim3 grid((unsigned)(a.RB * a.NG), (unsigned)gy, (unsigned)gz);
@@ -598,7 +608,7 @@ int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gou
   }
   PCMI_LAUNCH_CHECK();
   const int64_t per_k = (int64_t)cin * cout;
-  wgrad_slab_sum_kernel<<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)map->K), 256, 0, st>>>(a.slabs, a.RB, per_k, gweight, accumulate);
+  wgrad_slab_sum_kernel<<<dim3((unsigned)ceil_div(per_k, 32), (unsigned)K), 256, 0, st>>>(a.slabs, a.RB, per_k, gweight, accumulate);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

@@ -1352,6 +1352,31 @@ def test_wgrad_x3t_split_precision_matches_fp64(ME, size, cin, cout, form, monke
     assert rel_err(res["1"][k], g64[k]) <= 1e-5, "offset %d: %s" % (k, what)
 
 
+@pytest.mark.parametrize("n,cin,cout", [(20000, 128, 96), (47000, 128, 96), (9000, 192, 128), (8192, 64, 128), (174751, 128, 96)])
+def test_dense_1x1_weight_gradient_on_the_split_kernel(n, cin, cout, monkeypatch):
+  """gW = X^T G of a 1x1 convolution (the residual blocks' downsample layers, pc/model/resnet.py) on the tile-stationary
+  split-precision kernel with K = 1 and the identity table (csrc/spconv_wgrad_x3.hip, round 5) against the fp32 pair-list
+  kernel (PCMI_WGRAD_X3T_DENSE=0) and a float64 product, operands with a wide dynamic range."""
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(n)
+  x = torch.randn(n, cin, device=DEV) * torch.exp(torch.randn(n, 1, device=DEV))
+  g = torch.randn(n, cout, device=DEV) * torch.exp(0.5 * torch.randn(n, 1, device=DEV))
+  W = torch.randn(cin, cout, device=DEV) / cin ** 0.5
+  g64 = x.double().t() @ g.double()
+  res = {}
+  for mode in ("0", "1"):
+    monkeypatch.setenv("PCMI_WGRAD_X3T_DENSE", mode)
+    Wm = W.clone().requires_grad_(True)
+    y = PF.SparseConvFunction.apply(x, Wm, None, None, False, n, None)
+    y.backward(g)
+    torch.cuda.synchronize()
+    res[mode] = Wm.grad.clone()
+  e = {"fp32": rel_err(res["0"], g64), "x3": rel_err(res["1"], g64)}
+  print("dense wgrad %d x %d->%d vs float64: %s" % (n, cin, cout, {k: "%.2e" % v for k, v in e.items()}))
+  assert not torch.equal(res["0"], res["1"]), "PCMI_WGRAD_X3T_DENSE did not switch kernels"
+  assert e["fp32"] <= 1e-5 and e["x3"] <= max(4 * e["fp32"], 2e-6), e
+
+
 def test_engine_prepacked_weights_are_bit_identical(ME, monkeypatch):
   """The native executor packs the weights of every split-precision layer in ONE launch at the top of a forward pass
   (engine.hip: x3_prepack; both orientations, read by the forward and the backward-data launches of that iteration)
