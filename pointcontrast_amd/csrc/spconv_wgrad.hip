@@ -551,79 +551,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// The stem's weight gradient (3 input channels), ROW-stationary (round 5).  stem_wgrad_kernel above walks the pair list
-// of one offset per workgroup and reads the 128-byte gradient row of every PAIR: a row is fetched once per offset it
-// occurs in (~17 times; 450 MB for 22 MB of gradient rows: 165 us at level 1) -- and this is the LAST weight gradient of
-// a backward pass, i.e. what the optimiser waits for once the chain has finished.  Here a thread owns output channel n and
-// every 8th row of a row block, loads g[r][n] ONCE, walks the row's K table entries (the same address for the 32 lanes
-// of a row: one request) and keeps all K x 3 sums in registers; the row lanes are folded by a shuffle + LDS in a fixed
-// order, a workgroup leaves one [K][3][32] slab, stem_rows_reduce_kernel adds the slabs in block order.  Deterministic.
-template <int CIN, int KV>
-__global__ __launch_bounds__(256) void stem_wgrad_rows_kernel(const float* __restrict__ x, int64_t x_ld, const float* __restrict__ g,
-                                                              int64_t g_ld, const int32_t* __restrict__ nbr, int64_t n_rows,
-                                                              int cout, int rows_per_block, float* __restrict__ slabs) {
-  constexpr int E = KV * CIN;
-  __shared__ float s_part[4][E][32];
-  const int t = threadIdx.x, lane32 = t & 31, sub = t >> 5, wave = t >> 6;
-  const int n = (int)blockIdx.y * 32 + lane32;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + (int64_t)rows_per_block, n_rows);
-  float acc[KV][CIN];
-#pragma unroll
-  for (int k = 0; k < KV; ++k)
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) acc[k][c] = 0.f;
-  for (int64_t r = r0 + sub; r < r1; r += 8) {
-    const float gv = g[r * g_ld + n];
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-      const int32_t i = nbr[(int64_t)k * n_rows + r];
-      if (i >= 0) {
-        const float* xp = x + (int64_t)i * x_ld;
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) acc[k][c] = fmaf(xp[c], gv, acc[k][c]);
-      }
-    }
-  }
-  // the two row lanes of a wave (lanes n and n + 32), then the four waves through LDS, in wave order
-#pragma unroll
-  for (int k = 0; k < KV; ++k)
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      const float o = __shfl_xor(acc[k][c], 32, 64);
-      const float lo = (t & 32) ? o : acc[k][c], hi = (t & 32) ? acc[k][c] : o;  // (same order in both lanes: sub even + sub odd)
-      acc[k][c] = lo + hi;
-    }
-  if ((t & 32) == 0) {
-#pragma unroll
-    for (int k = 0; k < KV; ++k)
-#pragma unroll
-      for (int c = 0; c < CIN; ++c) s_part[wave][k * CIN + c][lane32] = acc[k][c];
-  }
-  __syncthreads();
-  float* slab = slabs + ((int64_t)blockIdx.x * E) * cout;  // [E][cout]
-  for (int e = t; e < E * 32; e += 256) {
-    const int ee = e >> 5, nn = e & 31;
-    const float v = ((s_part[0][ee][nn] + s_part[1][ee][nn]) + s_part[2][ee][nn]) + s_part[3][ee][nn];
-    slab[(int64_t)ee * cout + (int)blockIdx.y * 32 + nn] = v;
-  }
-}
-
-// gw[e] (+)= sum over the row blocks of slab[b][e], in block order; 32 elements x 8 block lanes per workgroup
-__global__ __launch_bounds__(256) void stem_rows_reduce_kernel(const float* __restrict__ slabs, int nblocks, int64_t per,
-                                                               float* __restrict__ gw, int accumulate) {
-  __shared__ float s_p[8][33];
-  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
-  float s = 0.f;
-  if (e < per)
-    for (int b = cl; b < nblocks; b += 8) s += slabs[(int64_t)b * per + e];
-  s_p[cl][el] = s;
-  __syncthreads();
-  if (cl != 0 || e >= per) return;
-#pragma unroll
-  for (int q = 1; q < 8; ++q) s += s_p[q][el];
-  gw[e] = accumulate ? gw[e] + s : s;
-}
+// (Round 5 tried a ROW-stationary form of the stem's gradient -- a thread owning one output channel of every 8th row and
+// all 27 x 3 sums in registers, so that a gradient row is read once instead of once per offset it occurs in: 436 us
+// against the 166 us of stem_wgrad_kernel at 175k rows, 81 dependent accumulators per thread with two loads each and
+// nothing to hide them behind; the step lost 2.2 %.  profiles/r05k_stem_weight_gradient_row_stationary_ab.txt.  Removed.)
 
 // column sums (bias gradient): two-level, deterministic.  A workgroup sums its row block with 256 / c row lanes per
 // column (round 4 used one thread per column: 32 of 256 threads at c = 32, each walking its 171 rows alone -- 111 us
@@ -787,8 +718,7 @@ size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, in
   // spconv_wgrad_x3.hip (K = 1: the dense 1x1 form of the same kernel, up to 128 row blocks of one slab each)
   const size_t tiled = (K == 27 && n_in == n_out) ? wgrad_x3t_workspace(n_out, cin, cout)
                                                   : ((K == 1 && n_in == n_out) ? (size_t)128 * cin * cout * sizeof(float) : 0);
-  const size_t stem_rows = cin == 3 ? (size_t)1024 * K * cin * cout * sizeof(float) : 0;  // stem_wgrad_rows_kernel: <= 1024 row-block slabs
-  return std::max(std::max(pairwise, tiled), stem_rows) + (size_t)1024 * cout * sizeof(float);
+  return std::max(pairwise, tiled) + (size_t)1024 * cout * sizeof(float);
 }
 
 }  // namespace pcmi
@@ -986,26 +916,6 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   if (!transpose && !gbias && wgrad_x3t_eligible(map, n_in, n_out, cin, cout, in_ld, gout_ld) && in_ld % 4 == 0 &&
       gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0)
     return wgrad_x3t_run(in, in_ld, gout, gout_ld, n_out, cin, cout, map, gweight, accumulate, ws, ws_bytes, st);
-  // PCMI_STEM_WGRAD_ROWS=0: the pair-list form of the stem's gradient (A/B); read per call
-  const bool stem_rows = [] {
-    const char* e = getenv("PCMI_STEM_WGRAD_ROWS");
-    return !(e && e[0] == '0');
-  }();
-  if (stem_rows && cin == 3 && K == 27 && map && map->nbr && !transpose && map->stride == 1 && n_in == n_out && cout % 32 == 0 &&
-      !gbias) {
-    const int nblocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n_out, 64)));
-    const int rows_per_block = (int)ceil_div(n_out, nblocks);
-    const int nb = (int)ceil_div(n_out, rows_per_block);
-    const int64_t per = (int64_t)K * cin * cout;
-    PCMI_REQUIRE(ws && ws_bytes >= (size_t)nb * per * sizeof(float), PCMI_ERR_WORKSPACE, "spconv_bwd_weight (stem): workspace %zu < %zu bytes",
-                 ws_bytes, (size_t)nb * per * sizeof(float));
-    stem_wgrad_rows_kernel<3, 27><<<dim3((unsigned)nb, (unsigned)(cout / 32)), 256, 0, st>>>(in, in_ld, gout, gout_ld, map->nbr, n_out, cout,
-                                                                                            rows_per_block, (float*)ws);
-    PCMI_LAUNCH_CHECK();
-    stem_rows_reduce_kernel<<<(unsigned)ceil_div(per, 32), 256, 0, st>>>((const float*)ws, nb, per, gweight, accumulate);
-    PCMI_LAUNCH_CHECK();
-    return PCMI_OK;
-  }
   WgradArgs a;
   int CT = 1, NT = 1;
   int64_t nchunks = 0;

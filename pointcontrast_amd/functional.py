@@ -220,38 +220,43 @@ class GatherRowsFunction(Function):
     return dsrc, None
 
 
-class GatherPairFunction(Function):
-  """(F[idx_a], F[idx_b]) of ONE feature matrix -- the two clouds of a pair run as one two-segment tensor
-  (lib/ddp_trainer.py: misc.joint_pair), idx_b already shifted past the first cloud's rows -- with both gradients scattered
-  into ONE zero-filled buffer.  Through two GatherRowsFunction calls on the slices F[:n0] / F[n0:] autograd enqueued nine
-  kernels between the loss and the backward pass (two fills + two scatters of the halves, two more full-size fills + two
-  slice copies + an add: 92 us on the chain in profiles/r04zy_*); here: one fill, two scatters into disjoint row ranges."""
+class GatherManyFunction(Function):
+  """(F[idx_0], F[idx_1], ...) of ONE feature matrix -- the two clouds of a pair run as one two-segment tensor
+  (lib/ddp_trainer.py: misc.joint_pair), the second cloud's indices already shifted past the first cloud's rows -- with all
+  gradients scattered into ONE zero-filled buffer.  Through one GatherRowsFunction per index set on the slices F[:n0] /
+  F[n0:] autograd enqueued nine small kernels between the PointInfoNCE loss and the backward pass (two fills + two scatters
+  of the halves, two more full-size fills + two slice copies + an add: 92 us on the chain in profiles/r04zy_*; more for
+  the four index sets of the hardest-contrastive loss); here: one fill and one scatter per index set (a scatter adds to
+  what is there: index sets may share rows)."""
 
   @staticmethod
-  def forward(ctx, src, idx_a, idx_b):
-    require_cuda(src, "gather pair")
+  def forward(ctx, src, *idxs):
+    require_cuda(src, "gather many")
     src = _c(src)
-    idx_a = idx_a.to(device=src.device, dtype=torch.int64).contiguous()
-    idx_b = idx_b.to(device=src.device, dtype=torch.int64).contiguous()
+    idxs = tuple(i.to(device=src.device, dtype=torch.int64).contiguous() for i in idxs)
     c = src.shape[1]
     outs = []
-    for idx in (idx_a, idx_b):
+    for idx in idxs:
       out = torch.empty((idx.shape[0], c), dtype=torch.float32, device=src.device)
       check(lib.pcmi_gather_rows(ptr(src), src.stride(0), ptr(idx), idx.shape[0], c, ptr(out), c, cur_stream(src.device)))
       outs.append(out)
-    ctx.save_for_backward(idx_a, idx_b)
+    ctx.save_for_backward(*idxs)
     ctx.n_src = src.shape[0]
-    return outs[0], outs[1]
+    return tuple(outs)
 
   @staticmethod
   @once_differentiable
-  def backward(ctx, da, db):
-    idx_a, idx_b = ctx.saved_tensors
-    c = da.shape[1]
-    dsrc = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=da.device)
-    for idx, d in ((idx_a, _c(da)), (idx_b, _c(db))):  # (the scatter owns every destination row it touches: order-free)
+  def backward(ctx, *douts):
+    idxs = ctx.saved_tensors
+    c = douts[0].shape[1]
+    dsrc = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=douts[0].device)
+    for idx, d in zip(idxs, douts):  # in argument order (deterministic; rows shared between index sets accumulate)
+      d = _c(d)
       check(lib.pcmi_scatter_add_rows(ptr(d), d.stride(0), ptr(idx), d.shape[0], c, ptr(dsrc), c, cur_stream(d.device)))
-    return dsrc, None, None
+    return (dsrc,) + (None,) * len(idxs)
+
+
+GatherPairFunction = GatherManyFunction  # (the two-index-set case: q / k of the PointInfoNCE loss)
 
 
 class NCELossFunction(Function):

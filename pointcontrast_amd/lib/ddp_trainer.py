@@ -421,7 +421,9 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
       up = lambda a, dt, name: self._upload_any(host(a, dt), ("hardest", name, slot))
       out = dict(sel0=up(sel0, torch.int64, "sel0"), sel1=up(sel1, torch.int64, "sel1"),
                  pos0=up(sample[:, 0], torch.int64, "pos0"), pos1=up(sample[:, 1], torch.int64, "pos1"))
-      held = [out["sel0"], out["sel1"], out["pos0"], out["pos1"]]
+      # cloud 1's rows in the pair's ONE feature matrix (PF.GatherManyFunction; misc.joint_pair)
+      out["sel1_joint"], out["pos1_joint"] = out["sel1"] + N0, out["pos1"] + N0
+      held = [out["sel0"], out["sel1"], out["pos0"], out["pos1"], out["sel1_joint"], out["pos1_joint"]]
       if keys is None:
         pairs_d = up(pp.reshape(-1), torch.int32, "pairs").view(-1, 2)
         keys = PF.PairKeySet(pairs_d, max(N0, N1))
@@ -478,7 +480,7 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
     return self._upload_hardest(h["n"][0], h["n"][1], h["pp"], h["box"]["drawn"], h["plan"], h["slot"], keys=h["keys"])
 
   def contrastive_hardest_negative_loss(self, F0, F1, positive_pairs, num_pos=5192, num_hn_samples=2048,
-                                        draws=None, prepared=None):
+                                        draws=None, prepared=None, joint=None):
     """pc/lib/ddp_trainer.py:186-238.  positive_pairs: CPU int tensor / array [P,2].
     draws: optional dict(sel0, sel1, pos_sel) replacing the np.random.choice calls.
     prepared: the samples / key set of _prepare_loss (then positive_pairs, num_*, draws are not looked at)."""
@@ -495,8 +497,12 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
       torch.cuda.current_stream(F0.device).wait_event(prepared["event"])
     sel0_d, sel1_d, pos0_d, pos1_d, keys = (prepared[k] for k in ("sel0", "sel1", "pos0", "pos1", "keys"))
 
-    subF0, subF1 = PF.GatherRowsFunction.apply(F0, sel0_d), PF.GatherRowsFunction.apply(F1, sel1_d)
-    posF0, posF1 = PF.GatherRowsFunction.apply(F0, pos0_d), PF.GatherRowsFunction.apply(F1, pos1_d)
+    if joint is not None and "sel1_joint" in prepared:
+      # joint: the pair's one feature matrix [N0 + N1, c] (F0 / F1 are its two row ranges): four gathers, ONE gradient buffer
+      subF0, subF1, posF0, posF1 = PF.GatherManyFunction.apply(joint, sel0_d, prepared["sel1_joint"], pos0_d, prepared["pos1_joint"])
+    else:
+      subF0, subF1 = PF.GatherRowsFunction.apply(F0, sel0_d), PF.GatherRowsFunction.apply(F1, sel1_d)
+      posF0, posF1 = PF.GatherRowsFunction.apply(F0, pos0_d), PF.GatherRowsFunction.apply(F1, pos1_d)
     with torch.no_grad():
       D01min, D01ind = PF.pdist_argmin(posF0, subF1)
       D10min, D10ind = PF.pdist_argmin(posF1, subF0)
@@ -525,7 +531,8 @@ class HardestContrastiveLossTrainer(ContrastiveLossTrainer):
         F0, F1, prep["input"]["correspondences"],
         num_pos=self.config.trainer.num_pos_per_batch * self.batch_size,
         num_hn_samples=self.config.trainer.num_hn_samples_per_batch * self.batch_size, draws=draws,
-        prepared=prep.get("hardest"))
+        prepared=prep.get("hardest"),
+        joint=self._feats[0] if ("sj" in prep and len(self._feats) == 1 and self.config.misc.get("fused_pair_gather", True)) else None)
     loss = pos_loss + neg_loss
     mark("loss")
     result = self._backward_and_step(loss, {"loss": loss.detach(), "pos_loss": pos_loss.detach(),

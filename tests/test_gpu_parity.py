@@ -596,6 +596,41 @@ def test_gather_scatter_rows(n_src, n, c):
     assert np.array_equal(sd.grad.cpu().numpy(), serial), "scatter add: not the row-ordered sum"
 
 
+def test_gather_many_shares_one_gradient_buffer():
+  """PF.GatherManyFunction: several index sets into ONE matrix (the pair as one two-segment tensor), all gradients
+  scattered into one buffer -- index sets that share rows must accumulate, and the result must equal what the
+  per-set GatherRowsFunction path (one buffer per set, added by autograd) gives."""
+  from pointcontrast_amd import functional as PF
+  torch.manual_seed(3)
+  n_src, c = 5000, 32
+  src = torch.randn(n_src, c)
+  sets = [torch.randint(0, n_src, (n,)) for n in (4096, 1000, 4097, 1)]
+  sets[1][:500] = sets[0][:500]  # rows shared between two sets
+  gs = [torch.randn(len(i), c) for i in sets]
+  a = src.to(DEV).requires_grad_(True)
+  outs = PF.GatherManyFunction.apply(a, *[i.to(DEV) for i in sets])
+  for o, i in zip(outs, sets):
+    assert torch.equal(o.cpu(), src[i])
+  torch.autograd.backward(list(outs), [g.to(DEV) for g in gs])
+  b = src.to(DEV).requires_grad_(True)
+  outs_b = [PF.GatherRowsFunction.apply(b, i.to(DEV)) for i in sets]
+  torch.autograd.backward(outs_b, [g.to(DEV) for g in gs])
+  ref = torch.zeros(n_src, c, dtype=torch.float64)
+  for i, g in zip(sets, gs):
+    ref.index_add_(0, i, g.double())
+  assert_close(a.grad, ref.float(), 1e-5, "gather many: gradient")
+  assert_close(a.grad, b.grad, 1e-6, "gather many vs one buffer per set")
+  a.grad = None
+  outs = PF.GatherManyFunction.apply(a, *[i.to(DEV) for i in sets])
+  first = None
+  for _ in range(2):
+    a.grad = None
+    outs = PF.GatherManyFunction.apply(a, *[i.to(DEV) for i in sets])
+    torch.autograd.backward(list(outs), [g.to(DEV) for g in gs])
+    first = a.grad.clone() if first is None else first
+  assert torch.equal(first, a.grad), "gather many: the gradient is not reproducible"
+
+
 def test_pdist_argmin_and_keyset():
   from pointcontrast_amd import functional as PF
   torch.manual_seed(0)
