@@ -551,10 +551,109 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// (Round 5 tried a ROW-stationary form of the stem's gradient -- a thread owning one output channel of every 8th row and
-// all 27 x 3 sums in registers, so that a gradient row is read once instead of once per offset it occurs in: 436 us
-// against the 166 us of stem_wgrad_kernel at 175k rows, 81 dependent accumulators per thread with two loads each and
-// nothing to hide them behind; the step lost 2.2 %.  profiles/r05k_stem_weight_gradient_row_stationary_ab.txt.  Removed.)
+// The stem's weight gradient (3 input channels) as ONE [K*3 x rows] @ [rows x 32] product on the fp32 matrix cores
+// (round 5).  stem_wgrad_kernel above walks the pair list of one offset per workgroup and reads the 128-byte gradient
+// row of every PAIR -- ~17 times per row, 380 MB for 22 MB of gradient rows, 165 us at 175k rows -- and this is the LAST
+// weight gradient of a backward pass: the chain has finished, the optimiser waits for it.  Here a workgroup takes
+// 64-row blocks: its 256 threads read the block's 27 x 64 entries of the offset-major neighbour table (64 consecutive
+// rows per wave: coalesced) and gather the 3 input channels of every present neighbour into an LDS tile
+// X81[row][3k + c] (absent: 0; columns 81..95 stay 0); wave w multiplies rows 16w..16w+15 -- v_mfma_f32_32x32x2_f32,
+// lane (i, h) supplies A = X81[row + h][32 mt + i] from LDS and B = g[row + h][n0 + i] straight from global memory, a
+// gradient row is read ONCE -- into three 32x32 accumulators (m = 3k + c padded to 96).  The four waves are added
+// through LDS in wave order, the workgroup leaves one [81][cout] slab, stem_slab_reduce_kernel adds the slabs in
+// workgroup order.  Deterministic; fp32 products and sums (the instruction wgrad_mfma_kernel uses).
+// (A first row-stationary form on the vector ALUs -- a thread owning one output channel of every 8th row and all 81
+//  sums in registers -- took 436 us: profiles/r05k_stem_weight_gradient_row_stationary_ab.txt.)
+template <int CIN, int KV>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, int64_t x_ld, const float* __restrict__ g,
+                                                              int64_t g_ld, const int32_t* __restrict__ nbr, int64_t n_rows,
+                                                              int cout, int64_t n_blocks, float* __restrict__ slabs) {
+  constexpr int E = KV * CIN;          // 81 rows of the gradient slice [K][CIN] x cout
+  constexpr int MT = (E + 31) / 32;    // 32-row accumulator tiles
+  constexpr int LD = 32 * MT + 1;      // (odd: lanes = consecutive rows write one column conflict-free)
+  constexpr int RB = 64;               // rows per block
+  constexpr int KJ = (KV + 3) / 4;     // table entries per thread and block (wave w: offsets w, w + 4, ...)
+  static_assert(96 * 33 <= RB * LD, "the wave reduction tile aliases the operand tile");
+  __shared__ float s_a[RB][LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 31, h = lane >> 5;
+  const int n0 = (int)blockIdx.y * 32;
+  for (int e = t; e < RB * (LD - E); e += 256) s_a[e / (LD - E)][E + e % (LD - E)] = 0.f;
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
+  for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+    const int64_t r0 = b * RB;
+    float bv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int64_t row = r0 + 16 * wave + 2 * s + h;
+      bv[s] = row < n_rows ? g[row * g_ld + n0 + i] : 0.f;
+    }
+    int32_t ix[KJ];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = wave + 4 * j;
+      ix[j] = (k < KV && r0 + lane < n_rows) ? nbr[(int64_t)k * n_rows + r0 + lane] : -1;
+    }
+    float xv[KJ][CIN];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) xv[j][c] = ix[j] >= 0 ? x[(int64_t)ix[j] * x_ld + c] : 0.f;
+    __syncthreads();  // the previous block's products have read the tile (first block: the zero columns are written)
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const int k = wave + 4 * j;
+      if (k < KV) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) s_a[lane][CIN * k + c] = xv[j][c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float* ar = &s_a[16 * wave + 2 * s + h][i];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[32 * mt], bv[s], acc[mt], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float (*s_red)[33] = reinterpret_cast<float (*)[33]>(&s_a[0][0]);
+  for (int src = 0; src < 4; ++src) {  // wave order: the same sum on every run
+    if (wave == src) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int row = 32 * mt + (j & 3) + 8 * (j >> 2) + 4 * h;  // (A role: m = 3k + c; column i: output channel)
+          s_red[row][i] = src == 0 ? acc[mt][j] : s_red[row][i] + acc[mt][j];
+        }
+    }
+    __syncthreads();
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * E * cout;  // [E][cout]
+  for (int e = t; e < E * 32; e += 256) slab[(int64_t)(e >> 5) * cout + n0 + (e & 31)] = s_red[e >> 5][e & 31];
+}
+
+// gw[e] (+)= sum over the workgroups of slab[b][e], in workgroup order; 32 elements x 8 slab lanes per workgroup
+__global__ __launch_bounds__(256) void stem_slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t per,
+                                                               float* __restrict__ gw, int accumulate) {
+  __shared__ float s_p[8][33];
+  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (e < per)
+    for (int b = cl; b < n_slabs; b += 8) s += slabs[(int64_t)b * per + e];
+  s_p[cl][el] = s;
+  __syncthreads();
+  if (cl != 0 || e >= per) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += s_p[q][el];
+  gw[e] = accumulate ? gw[e] + s : s;
+}
+constexpr int kStemSlabs = 512;  // workgroups (= slabs) of stem_wgrad_mfma_kernel: two per CU
 
 // column sums (bias gradient): two-level, deterministic.  A workgroup sums its row block with 256 / c row lanes per
 // column (round 4 used one thread per column: 32 of 256 threads at c = 32, each walking its 171 rows alone -- 111 us
@@ -718,7 +817,8 @@ size_t spconv_wgrad_workspace(int64_t n_in, int64_t n_out, int cin, int cout, in
   // spconv_wgrad_x3.hip (K = 1: the dense 1x1 form of the same kernel, up to 128 row blocks of one slab each)
   const size_t tiled = (K == 27 && n_in == n_out) ? wgrad_x3t_workspace(n_out, cin, cout)
                                                   : ((K == 1 && n_in == n_out) ? (size_t)128 * cin * cout * sizeof(float) : 0);
-  return std::max(pairwise, tiled) + (size_t)1024 * cout * sizeof(float);
+  const size_t stem_slabs = cin == 3 ? (size_t)kStemSlabs * K * cin * cout * sizeof(float) : 0;  // stem_wgrad_mfma_kernel
+  return std::max(std::max(pairwise, tiled), stem_slabs) + (size_t)1024 * cout * sizeof(float);
 }
 
 }  // namespace pcmi
@@ -916,6 +1016,24 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   if (!transpose && !gbias && wgrad_x3t_eligible(map, n_in, n_out, cin, cout, in_ld, gout_ld) && in_ld % 4 == 0 &&
       gout_ld % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)gout % 16 == 0)
     return wgrad_x3t_run(in, in_ld, gout, gout_ld, n_out, cin, cout, map, gweight, accumulate, ws, ws_bytes, st);
+  // PCMI_STEM_WGRAD_MFMA=0: the pair-list form of the stem's gradient (A/B); read per call
+  const bool stem_mfma = [] {
+    const char* e = getenv("PCMI_STEM_WGRAD_MFMA");
+    return !(e && e[0] == '0');
+  }();
+  if (stem_mfma && cin == 3 && K == 27 && map && map->nbr && !transpose && map->stride == 1 && n_in == n_out && cout % 32 == 0 &&
+      !gbias) {
+    const int64_t n_blocks = ceil_div(n_out, 64);
+    const int n_wg = (int)std::min<int64_t>(kStemSlabs, n_blocks);
+    PCMI_REQUIRE(ws && ws_bytes >= (size_t)n_wg * K * per_k * sizeof(float), PCMI_ERR_WORKSPACE,
+                 "spconv_bwd_weight (stem): workspace %zu < %zu bytes", ws_bytes, (size_t)n_wg * K * per_k * sizeof(float));
+    stem_wgrad_mfma_kernel<3, 27><<<dim3((unsigned)n_wg, (unsigned)(cout / 32)), 256, 0, st>>>(in, in_ld, gout, gout_ld, map->nbr, n_out,
+                                                                                            cout, n_blocks, (float*)ws);
+    PCMI_LAUNCH_CHECK();
+    stem_slab_reduce_kernel<<<(unsigned)ceil_div(K * per_k, 32), 256, 0, st>>>((const float*)ws, n_wg, K * per_k, gweight, accumulate);
+    PCMI_LAUNCH_CHECK();
+    return PCMI_OK;
+  }
   WgradArgs a;
   int CT = 1, NT = 1;
   int64_t nchunks = 0;
