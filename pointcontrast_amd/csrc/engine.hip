@@ -466,6 +466,7 @@ struct BackwardRun {
   // set by begin()
   hipStream_t st = nullptr, wst = nullptr;  // wst: the side stream of the op being differentiated (step)
   bool two_sides = false;
+  bool stem_on_chain = true;  // the input layer's weight gradient on the chain (see step())
   int64_t small_rows = 0;
   PassState* ps = nullptr;
   DevBuf* wws = nullptr;
@@ -537,6 +538,10 @@ struct BackwardRun {
       bn_par = e && e[0] == '1';
     }
     two_sides = debug_env_long("PCMI_WGRAD_SIDE2") != 0;
+    {
+      const char* e = getenv("PCMI_STEM_WGRAD_ON_CHAIN");
+      stem_on_chain = !(e && e[0] == '0');
+    }
     rc = ensure_streams(n, two_sides);
     if (rc) return rc;
     small_rows = 8192;  // (= the default of PCMI_WGRAD_X3T: what is under it takes the pair-list kernel)
@@ -598,11 +603,21 @@ struct BackwardRun {
       if (!grouped) {
       const int sq = (two_sides && (std::min(n_in, n_out) < small_rows || op.kernel_size != 3 || op.stride != 1 ||
                                     std::min(op.cin, op.cout) < 64)) ? 1 : 0;
-      wst = n.side[sq];
-      wws = &n.ws_side[sq];
-      PCMI_HIP_CHECK(hipEventRecord(n.ev_main[sq], st));
-      PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sq], 0));
-      pending[sq] = used[sq] = true;
+      // The layer that reads the network's input is the LAST op of a backward pass: nothing is left on the chain that its
+      // weight gradient could run beside, the pass's join follows.  On the side stream it cost two event hand-overs
+      // (chain -> side -> chain, ~10 us each in the kernel trace) for 50 us of work: it stays on the chain, with the chain's
+      // workspace.  PCMI_STEM_WGRAD_ON_CHAIN=0: on the side stream like every other weight gradient (A/B; read per pass).
+      const bool on_chain = op.in == n.input_tensor && stem_on_chain;
+      if (on_chain) {
+        wst = st;
+        wws = &ps->ws;
+      } else {
+        wst = n.side[sq];
+        wws = &n.ws_side[sq];
+        PCMI_HIP_CHECK(hipEventRecord(n.ev_main[sq], st));
+        PCMI_HIP_CHECK(hipStreamWaitEvent(wst, n.ev_main[sq], 0));
+        pending[sq] = used[sq] = true;
+      }
       const int tw = n.timed_slot(i);
       if (tw >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tw + 4], wst));
       rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose, grads + op.w_off,

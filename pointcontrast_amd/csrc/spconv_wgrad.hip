@@ -637,20 +637,22 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
   for (int e = t; e < E * 32; e += 256) slab[(int64_t)(e >> 5) * cout + n0 + (e & 31)] = s_red[e >> 5][e & 31];
 }
 
-// gw[e] (+)= sum over the workgroups of slab[b][e], in workgroup order; 32 elements x 8 slab lanes per workgroup
+// gw[e] (+)= sum over the workgroups of slab[b][e]: 8 elements x 32 slab lanes per workgroup (lane q adds slabs q, q + 32,
+// ... in that order, the lanes are added in lane order: the same sum on every run).  512 slabs of 10 KB: 16 dependent adds
+// per thread instead of the 64 of an 8-lane split -- this launch is the last thing the optimiser waits for.
 __global__ __launch_bounds__(256) void stem_slab_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t per,
                                                                float* __restrict__ gw, int accumulate) {
-  __shared__ float s_p[8][33];
-  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  __shared__ float s_p[32][9];
+  const int el = threadIdx.x & 7, cl = threadIdx.x >> 3;
+  const int64_t e = (int64_t)blockIdx.x * 8 + el;
   float s = 0.f;
   if (e < per)
-    for (int b = cl; b < n_slabs; b += 8) s += slabs[(int64_t)b * per + e];
+    for (int b = cl; b < n_slabs; b += 32) s += slabs[(int64_t)b * per + e];
   s_p[cl][el] = s;
   __syncthreads();
   if (cl != 0 || e >= per) return;
 #pragma unroll
-  for (int q = 1; q < 8; ++q) s += s_p[q][el];
+  for (int q = 1; q < 32; ++q) s += s_p[q][el];
   gw[e] = accumulate ? gw[e] + s : s;
 }
 constexpr int kStemSlabs = 512;  // workgroups (= slabs) of stem_wgrad_mfma_kernel: two per CU
@@ -1024,13 +1026,15 @@ int spconv_backward_weight_m32(const float* in, int64_t in_ld, int64_t n_in, int
   if (stem_mfma && cin == 3 && K == 27 && map && map->nbr && !transpose && map->stride == 1 && n_in == n_out && cout % 32 == 0 &&
       !gbias) {
     const int64_t n_blocks = ceil_div(n_out, 64);
-    const int n_wg = (int)std::min<int64_t>(kStemSlabs, n_blocks);
+    int slabs_max = kStemSlabs;
+    if (const char* e = getenv("PCMI_STEM_SLABS")) slabs_max = std::max(1, std::min(kStemSlabs, atoi(e)));  // (tuning; <= the workspace's 512)
+    const int n_wg = (int)std::min<int64_t>(slabs_max, n_blocks);
     PCMI_REQUIRE(ws && ws_bytes >= (size_t)n_wg * K * per_k * sizeof(float), PCMI_ERR_WORKSPACE,
                  "spconv_bwd_weight (stem): workspace %zu < %zu bytes", ws_bytes, (size_t)n_wg * K * per_k * sizeof(float));
     stem_wgrad_mfma_kernel<3, 27><<<dim3((unsigned)n_wg, (unsigned)(cout / 32)), 256, 0, st>>>(in, in_ld, gout, gout_ld, map->nbr, n_out,
                                                                                             cout, n_blocks, (float*)ws);
     PCMI_LAUNCH_CHECK();
-    stem_slab_reduce_kernel<<<(unsigned)ceil_div(K * per_k, 32), 256, 0, st>>>((const float*)ws, n_wg, K * per_k, gweight, accumulate);
+    stem_slab_reduce_kernel<<<(unsigned)ceil_div(K * per_k, 8), 256, 0, st>>>((const float*)ws, n_wg, K * per_k, gweight, accumulate);
     PCMI_LAUNCH_CHECK();
     return PCMI_OK;
   }
