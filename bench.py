@@ -228,12 +228,23 @@ def kernel_rooflines(batch, device, joint=True):
   qn = torch.nn.functional.normalize(torch.randn(4096, 32, device=device), dim=1).requires_grad_(True)
   kn = torch.nn.functional.normalize(torch.randn(4096, 32, device=device), dim=1).requires_grad_(True)
 
+  # The two C-ABI calls directly, on preallocated buffers.  (Through autograd -- Function.apply + .backward(), two allocator
+  # round trips and ~10 small torch ops per iteration on the host -- the 4 launches of ~20 us each were HOST-bound: the same
+  # build read 0.088 ms in one process and 0.2215 ms in another)
+  qd, kd = qn.detach().contiguous(), kn.detach().contiguous()
+  lse = torch.empty(4096, dtype=torch.float32, device=device)
+  lossv = torch.empty((), dtype=torch.float32, device=device)
+  gone = torch.ones((), dtype=torch.float32, device=device)
+  dq, dk = torch.empty_like(qd), torch.empty_like(kd)
+  nws, nwsb = ws_args(lib.pcmi_nce_workspace_bytes(4096, 32), device)
+  sn = cur_stream(device)
+
   def nce_step():
-    qn.grad = kn.grad = None
-    PF.NCELossFunction.apply(qn, kn, 0.4).backward()
+    check(lib.pcmi_nce_fwd(ptr(qd), ptr(kd), 4096, 32, 1.0 / 0.4, ptr(lse), ptr(lossv), nws, nwsb, sn))
+    check(lib.pcmi_nce_bwd(ptr(qd), ptr(kd), ptr(lse), 4096, 32, 1.0 / 0.4, ptr(gone), ptr(dq), ptr(dk), nws, nwsb, sn))
 
   print("[bench] timing nce", file=sys.stderr, flush=True)
-  t = time_kernel(nce_step)
+  t = time_kernel(nce_step, iters=100)
   fl = 5 * 2 * 4096 * 4096 * 32
   # (pack + forward, pack + backward: 4 launches; the time is launch / cross-workgroup hand-off latency, not matrix work:
   #  profiles/r04n_nce_component_removal.txt)
@@ -287,7 +298,7 @@ def cpu_baseline(batch_size_sample=1):
     times.append(time.perf_counter() - t0)
   timed = times[1:]
   return {"value": round(batch_size_sample * len(timed) / sum(timed), 4), "unit": "scene-pairs/sec",
-          "cores": torch.get_num_threads(), "kind": "port",
+          "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
           "sample": "%d pair(s) (N0=%d, N1=%d voxels), full oracle iteration (2 fwd + NCE + bwd + SGD), 1 untimed + %d "
                     "timed (%s s each), time.perf_counter"
                     % (batch_size_sample, b["sinput0_C"].shape[0], b["sinput1_C"].shape[0], len(timed),
@@ -303,10 +314,10 @@ def run_cpu_baseline_bounded(limit_s=300):
     for line in r.stdout.splitlines():
       if line.startswith("CPUBASE"):
         return json.loads(line[len("CPUBASE"):])
-    return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "kind": "port",
+    return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "cpu baseline failed: " + (r.stderr or "")[-200:]}
   except subprocess.TimeoutExpired:
-    return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "kind": "port",
+    return {"value": None, "unit": "scene-pairs/sec", "cores": 0, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "1 pair did not finish within %d s on this host" % limit_s}
 
 

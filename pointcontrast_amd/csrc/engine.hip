@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "internal.h"
@@ -69,12 +70,16 @@ static int host_wait_event(hipEvent_t ev) {
     PCMI_HIP_CHECK(hipEventSynchronize(ev));
     return PCMI_OK;
   }
+  // (tv_nsec must stay below one second: a larger PCMI_THROTTLE_SLEEP_US goes into tv_sec, or nanosleep returns EINVAL at once
+  //  and the loop spins on hipEventQuery)
+  const struct timespec ts = {(time_t)(us / 1000000L), (us % 1000000L) * 1000L};
   for (;;) {
     const hipError_t q = hipEventQuery(ev);
     if (q == hipSuccess) return PCMI_OK;
     if (q != hipErrorNotReady) PCMI_HIP_CHECK(q);
-    (void)hipGetLastError();  // hipErrorNotReady is sticky in hipGetLastError: PCMI_LAUNCH_CHECK must not see it
-    struct timespec ts = {0, us * 1000L};
+    // hipErrorNotReady is recorded as this thread's last error and PCMI_LAUNCH_CHECK must not see it -- but only THAT is
+    // dropped: a genuine error of an earlier asynchronous launch stays for the next check to find
+    if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
     nanosleep(&ts, nullptr);
   }
 }
@@ -163,7 +168,8 @@ struct PassState {
   // stream; the backward-data orientations [x3_items_fwd, x3_items) -- not needed before the backward pass -- are packed
   // on the executor's side stream while the forward pass is in its coarse levels (PCMI_X3_PACK_SPLIT=0: all at the top).
   int64_t x3_items_fwd = 0;
-  bool x3_bwd_pending = false;       // this pass's forward still owes the backward orientations
+  bool x3_bwd_owed = false;          // this pass's forward still has to enqueue the backward orientations
+  bool x3_bwd_pending = false;       // ... they are enqueued on the side stream and x3_bwd_packed is recorded behind them
   hipEvent_t x3_bwd_packed = nullptr;  // ... recorded behind them on the side stream: the backward pass waits for it
   // the job table goes up through pinned host memory with an asynchronous copy ON the pass's stream: ordered behind
   // the pack kernel of the previous table still queued there, and the enqueueing thread does not wait for the queue
@@ -289,6 +295,7 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
   const bool enabled = !(pe && pe[0] == '0');
   ps.x3_current = false;
   ps.x3_bwd_pending = false;
+  ps.x3_bwd_owed = false;
   if (!enabled || !pcmi_spconv_split_precision()) {
     x3_set_prepacked(nullptr, 0);
     return PCMI_OK;
@@ -379,7 +386,10 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
   const int64_t upto = split_bwd ? ps.x3_items_fwd : ps.x3_items;
   const int rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(ps.x3_jobs_dev.p), ps.x3_n_jobs, upto, st);
   if (rc) return rc;
-  ps.x3_bwd_pending = split_bwd && ps.x3_items > ps.x3_items_fwd;
+  // (the forward pass still OWES the backward orientations; x3_bwd_pending -- "an event to wait for exists" -- is set only
+  //  once they have been enqueued and the event recorded, pcmi_net_forward: a pass that fails in between must not leave a
+  //  stale event to be waited for as if the packs were those of its weights -- ADVICE round 5)
+  ps.x3_bwd_owed = split_bwd && ps.x3_items > ps.x3_items_fwd;
   ps.x3_current = true;
   x3_set_prepacked(ps.x3_table.data(), (int)ps.x3_table.size());
   return PCMI_OK;
@@ -592,7 +602,12 @@ struct BackwardRun {
       // a coarse-level 3^3 layer: its gradient joins the open group and is launched with the others of its run (at the
       // next layer that does not fit the group, at a bucket boundary, or at the end of the pass)
       bool grouped = false;
-      if (!two_sides && !op.transpose && op.kernel_size == 3 && op.stride == 1 && !op.has_bias && map && n.timed_slot(i) < 0) {
+      // PCMI_DEBUG_SKIP_WGRAD_ROWS=<n> (timing diagnostic, WRONG gradients): the weight gradients of layers with at least n
+      // rows on both sides are not launched at all (1 = none is) -- what the chain costs without them beside it
+      // (profiles/r06a_*: the bound of moving the level-1 weight gradients out of the backward pass)
+      const long skip_rows = debug_env_long("PCMI_DEBUG_SKIP_WGRAD_ROWS");
+      const bool skip_wgrad = skip_rows > 0 && std::min(n_in, n_out) >= skip_rows && op.in != n.input_tensor;
+      if (!skip_wgrad && !two_sides && !op.transpose && op.kernel_size == 3 && op.stride == 1 && !op.has_bias && map && n.timed_slot(i) < 0) {
         grouped = wgrad_group_add(n.wgroup, x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, grads + op.w_off, 1, n.side[0]);
         if (!grouped && wgrad_group_size(n.wgroup) > 0) {  // another tile shape, or the group is full: launch it, start a new one
           rc = flush_group();
@@ -600,7 +615,7 @@ struct BackwardRun {
           grouped = wgrad_group_add(n.wgroup, x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, grads + op.w_off, 1, n.side[0]);
         }
       }
-      if (!grouped) {
+      if (!grouped && !skip_wgrad) {
       const int sq = (two_sides && (std::min(n_in, n_out) < small_rows || op.kernel_size != 3 || op.stride != 1 ||
                                     std::min(op.cin, op.cout) < 64)) ? 1 : 0;
       // The layer that reads the network's input is the LAST op of a backward pass: nothing is left on the chain that its
@@ -945,8 +960,18 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   if (rc) return rc;
   // where the backward-data orientations are packed: behind the first op of the third level (the pass is in its
   // latency-bound coarse phase from there on and the side stream is idle during a forward pass) -- or behind the last op
+  // an error return from here on leaves no table behind that a later pass could mistake for this one's packs
+  struct X3FailGuard {
+    PassState& ps;
+    bool armed = true;
+    ~X3FailGuard() {
+      // (x3_bwd_pending stays: it is true only if THIS pass recorded the event, and the next forward of the pass must still
+      //  wait for that side-stream pack before it rebuilds the job table)
+      if (armed) ps.x3_current = ps.x3_bwd_owed = false;
+    }
+  } x3_guard{ps};
   int pack_bwd_at = -1;
-  if (ps.x3_bwd_pending) {
+  if (ps.x3_bwd_owed) {
     pack_bwd_at = n_ops - 1;
     for (int i = 0; i < n_ops; ++i)
       if (n.tensors[n.ops[i].out].level >= 2) {
@@ -958,6 +983,49 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     if (!ps.x3_bwd_packed) PCMI_HIP_CHECK(hipEventCreateWithFlags(&ps.x3_bwd_packed, hipEventDisableTiming));
   }
   g_prof_fwd.lap(2);
+  // PCMI_DEBUG_LATE_WGRAD=<rows> (timing prototype, WRONG results; use with PCMI_DEBUG_SKIP_WGRAD_ROWS=<rows>): the weight
+  // gradients of the layers with at least <rows> rows on both sides -- which the backward pass then leaves out -- are
+  // launched HERE, on the side stream beside the forward pass, into a scratch buffer (operands: whatever the arenas hold),
+  // and the pass waits for them in front of the first such layer: the schedule of "the level-1 weight gradients of
+  // iteration i run beside the forward pass of iteration i + 1 and their layers are updated before it reaches them",
+  // without the trainer-side plumbing.  profiles/r06b_*.
+  int late_first_op = -1;
+  if (const long late_rows = debug_env_long("PCMI_DEBUG_LATE_WGRAD"); late_rows > 0 && train0 && ps.grad.p && !ps.grad_off.empty()) {
+    rc = ensure_streams(n, false);
+    if (rc) return rc;
+    static DevBuf late_scratch;
+    rc = late_scratch.reserve((size_t)27 * 256 * 256 * sizeof(float), st);
+    if (rc) return rc;
+    rc = n.ws_side[0].reserve(ps.ws.cap, n.side[0]);
+    if (rc) return rc;
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
+    const bool late_fp32 = debug_env_long("PCMI_DEBUG_LATE_FP32") != 0;  // the pair-list fp32 kernel for them (small workgroups)
+    const char* x3t_env = getenv("PCMI_WGRAD_X3T");
+    const std::string x3t_saved = x3t_env ? x3t_env : "";
+    if (late_fp32) setenv("PCMI_WGRAD_X3T", "0", 1);
+    struct RestoreEnv {
+      bool on, had;
+      const std::string& v;
+      ~RestoreEnv() {
+        if (!on) return;
+        if (had) setenv("PCMI_WGRAD_X3T", v.c_str(), 1); else unsetenv("PCMI_WGRAD_X3T");
+      }
+    } restore{late_fp32, x3t_env != nullptr, x3t_saved};
+    for (int i = n_ops - 1; i >= 0; --i) {
+      const auto& op = n.ops[i];
+      if (op.type != PCMI_OP_CONV || op.in == n.input_tensor) continue;
+      const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
+      if (std::min(n_in, n_out) < late_rows) continue;
+      late_first_op = i;
+      const View x = act_view(n, ps, op.in);
+      const View dy = grad_view(n, ps, op.out, out_feats, out_ld);
+      rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
+                                  op.transpose, (float*)late_scratch.p, nullptr, 0, n.ws_side[0].p, n.ws_side[0].cap, n.side[0]);
+      if (rc) return rc;
+    }
+    if (late_first_op >= 0) PCMI_HIP_CHECK(hipEventRecord(n.ev_side[0], n.side[0]));
+  }
   // ---- run --------------------------------------------------------------------------------------
   if (!n.timed_ops.empty()) {  // the next event set of the ring (pcmi_net_time_ops); its old records are dropped
     ++n.timed_cur;
@@ -968,6 +1036,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     const auto& op = n.ops[i];
     const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
+    if (i == late_first_op) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));  // (PCMI_DEBUG_LATE_WGRAD)
     if (op.type == PCMI_OP_CONV) {
       const int tq = n.timed_slot(i);
       if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 0], st));
@@ -1014,6 +1083,8 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       rc = x3_pack_many(reinterpret_cast<const X3PackJob*>(ps.x3_jobs_dev.p), ps.x3_n_jobs, ps.x3_items, n.side[0], ps.x3_items_fwd);
       if (rc) return rc;
       PCMI_HIP_CHECK(hipEventRecord(ps.x3_bwd_packed, n.side[0]));
+      ps.x3_bwd_owed = false;
+      ps.x3_bwd_pending = true;
     }
     g_prof_fwd.lap(op.type == PCMI_OP_CONV ? 3 : (op.type == PCMI_OP_BN ? 4 : 5));
   }
@@ -1030,6 +1101,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   static const char* const kFwdNames[] = {"levels", "maps", "layout+reserve", "conv", "bn", "l2norm", "tail"};
   g_prof_fwd.report("net_forward", kFwdNames, 7);
   ps.valid = train;
+  x3_guard.armed = false;
   return PCMI_OK;
 }
 

@@ -951,8 +951,11 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ a
 // PCMI_BN_FUSED_FINAL=1: the statistics launch merges its own partials (last-arriving workgroup) instead of leaving
 // them to colreduce_final_kernel -- the round-1..3 form, kept for the A/B (see colreduce_final_kernel)
 // PCMI_BN_LEAN_ROWS: from this many rows the backward statistics take the 48-register form of colreduce_partial_kernel
-// (0 = never).  Read per call (A/B in one process).  Same sums in the same order: the row lanes and blocks are
-// unchanged, only how many of a thread's rows are in flight at once.
+// (0 = never).  Read per call (A/B in one process).  Same row blocks and the same partial layout, but NOT the same
+// summation order inside a block: the lean kernel has 256 / (c / 2) row lanes where the wide one has 256 / (c / 4), so the
+// last bits of dgamma / dbeta / dx change where n crosses this threshold (the one-launch kernels at PCMI_BN_SMALL_ROWS /
+// _BWD_ROWS likewise).  Every form is deterministic for a given input; the result is not invariant under the row count
+// (the golden traces were recorded with the default thresholds).
 static int64_t bn_lean_rows() {
   const char* e = getenv("PCMI_BN_LEAN_ROWS");
   return e ? (int64_t)atoll(e) : (int64_t)65536;

@@ -840,8 +840,29 @@ static bool sk_rows_eligible(int64_t rows, int K) {
   const int64_t mt = sk_min_tiles();
   return K > 1 && mt > 0 && rows >= 4096 /* kSortRowsMin: such maps carry tile units */ && ceil_div(rows, 128) >= mt;
 }
+// PCMI_SK_MID=<tiles>: the unit-balanced launch ALSO for the levels whose whole-tile launch would split its offsets over
+// blockIdx.z (ksplit > 1: fewer tiles than 2.5 workgroups per compute unit), from <tiles> 128-row tiles up (0 = off).
+// There the offset split gives every blockIdx.z the same NUMBER of offsets whatever their occupancy, rounds the grid to
+// whole residency rounds and leaves ksplit full-size partial tensors to split_reduce_kernel; the unit-balanced launch
+// gives every workgroup the same number of occupied (tile, offset, chunk) steps and only the tiles shared between
+// workgroups go through partial slots (sk_fixup_kernel).  PCMI_SK_MID_STEPS: chunk steps a workgroup should get at least
+// (the grid shrinks below the resident maximum when a level has fewer).  Read per call.
+static int64_t sk_mid_tiles() {
+  const char* e = getenv("PCMI_SK_MID");
+  return e ? (int64_t)atoll(e) : 0;
+}
+static bool sk_mid_eligible(int64_t rows, int K) {
+  const int64_t mt = sk_mid_tiles();
+  return K > 1 && mt > 0 && rows >= 4096 && ceil_div(rows, 128) >= mt;
+}
+static int sk_mid_grid(int G_max, int64_t n_tiles, int K, int nch) {
+  const char* e = getenv("PCMI_SK_MID_STEPS");
+  const int64_t steps = std::max<int64_t>(1, e ? atoll(e) : 16);
+  const int64_t want = ceil_div(n_tiles * K * nch, steps);
+  return (int)std::max<int64_t>(8, std::min<int64_t>(G_max, ceil_div(want, 8) * 8));
+}
 static size_t sk_partial_bytes(int64_t rows, int N, int K) {
-  return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups_max() * 2 * 128 * N * sizeof(float) : 0;
+  return (sk_rows_eligible(rows, K) || sk_mid_eligible(rows, K)) ? (size_t)sk_workgroups_max() * 2 * 128 * N * sizeof(float) : 0;
 }
 
 // The 16-row kernels take the 128-row tiles of levels with at least PCMI_CONV16 rows (0 = never, 1 = always).  Default
@@ -1045,10 +1066,12 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   // (the unit-balanced launch exists for the 16-row kernels: an operand of >= 2 GiB, which they cannot address, takes the
   //  whole-tile launch of spconv_mfma_kernel below)
-  if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
+  const bool sk_mid = p.ksplit > 1 && sk_mid_eligible(n_rows, a.K);
+  if (map && map->tile_pref && map->perm && p.RW == 4 && ((p.ksplit == 1 && sk_rows_eligible(n_rows, a.K)) || sk_mid) &&
       map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64 && conv16_enabled(n_rows, x_rows * x_ld * 4)) {
     const bool x3 = conv16_x3(p.NT, C, N);
-    const int G = x3 ? x3_workgroups(p.NT) : sk_workgroups(p.NT);
+    int G = x3 ? x3_workgroups(p.NT) : sk_workgroups(p.NT);
+    if (sk_mid) G = sk_mid_grid(G, map->n_tiles, a.K, C / kKC);
     const size_t part = sk_partial_bytes(n_rows, N, a.K);
     const size_t need = part + (x3 ? x3_pack_bytes(a.K, C, N) : 0);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);

@@ -272,6 +272,9 @@ class NativeEngine:
       rc = lib.pcmi_net_backward(self._h, pass_id, ptr(d), d.stride(0), ptr(self.flat.w), ptr(self.flat.g), lo_arr, nb, cb,
                                  None, cur_stream(d.device))
     self._held[pass_id] = None
+    if (errors or rc) and reducer is not None and reducer.active:
+      # the step is lost either way; leave the reducer in a state the NEXT step can start from
+      reducer.abort()
     if errors:  # raised inside a bucket callback: ctypes would have printed and dropped it
       raise errors[0]
     check(rc)

@@ -9,6 +9,7 @@ them); a bucket is all-reduced with RCCL on a side HIP stream as soon as its las
 has been accumulated; the 1/world scale is folded into the fused SGD step.
 One process per GPU (torchrun / RANK, LOCAL_RANK, WORLD_SIZE, MASTER_* from the environment).
 """
+import logging
 import os
 
 import torch
@@ -57,8 +58,17 @@ def init_process_group(proc_rank=None, world_size=None, backend=None):
   os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
   os.environ.setdefault("MASTER_PORT", "29500")
   cap = int(os.environ.get("PCMI_RCCL_MAX_CHANNELS", DEFAULT_RCCL_MAX_CHANNELS))
-  if use_cuda and cap > 0:
+  # The cap was tuned for ONE node (xGMI rings beside the weight-gradient kernel); between nodes the bandwidth of a ring
+  # depends on the channel count, so a multi-node world keeps RCCL's own choice unless the user asks.
+  # LOCAL_WORLD_SIZE is what torchrun / lib.multiprocessing export; without it the world is taken to be one node only
+  # when it fits this node's devices.
+  local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world if world <= max(torch.cuda.device_count(), 1) else 0) or 0)
+  single_node = local_world == world
+  if use_cuda and cap > 0 and (single_node or "PCMI_RCCL_MAX_CHANNELS" in os.environ):
     os.environ.setdefault("NCCL_MAX_NCHANNELS", str(cap))  # read by RCCL when the communicator is created
+    if rank == 0:
+      logging.getLogger(__name__).info("RCCL channel cap: NCCL_MAX_NCHANNELS=%s (%s)", os.environ["NCCL_MAX_NCHANNELS"],
+                                       "single node" if single_node else "PCMI_RCCL_MAX_CHANNELS set explicitly")
   dist.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
   return rank, world
 
@@ -197,6 +207,23 @@ class GradReducer:
     for w in self._works:
       w.wait()
     if self.cuda:
+      torch.cuda.current_stream(self.flat.g.device).wait_stream(self.comm_stream)
+    self._works = []
+    self._pending = [0] * len(self.buckets)
+    self._launched = [False] * len(self.buckets)
+
+  def abort(self):
+    """After a failure inside a step (a bucket callback raised, backward returned an error): waits for the all-reduces
+    that DID launch (the other ranks are inside them), orders the compute stream behind the communication stream and
+    forgets the step's bookkeeping -- the next step starts from a clean state instead of skipping the buckets this one
+    marked launched (it would then step on un-reduced gradients: silent divergence between the ranks).
+    The failed step's gradients are whatever they are: the caller must not apply them."""
+    for w in self._works:
+      try:
+        w.wait()
+      except Exception:  # noqa: BLE001  (a broken process group: nothing left to wait for)
+        pass
+    if self.cuda and self.active:
       torch.cuda.current_stream(self.flat.g.device).wait_stream(self.comm_stream)
     self._works = []
     self._pending = [0] * len(self.buckets)

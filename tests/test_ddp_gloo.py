@@ -33,6 +33,19 @@ def _worker(rank, world, port, q):
     flat.zero_grad()
     (model(x).pow(2).sum() + model(2 * x).sum()).backward()  # two uses of the shared weights
     red.finish()
+  # a step that fails after SOME buckets were launched (a bucket callback raised on every rank, NativeEngine.backward):
+  # abort() waits for what is in flight and forgets the step; the next step must reduce EVERY bucket again -- without it
+  # the buckets marked launched would be skipped and the ranks would step on un-reduced gradients
+  flat.zero_grad()
+  red._launch(0)
+  assert red._launched[0] and red._works
+  red.abort()
+  assert not any(red._launched) and not red._works and not any(red._pending)
+  flat.zero_grad()
+  n_before = red.n_launched_total
+  (model(x).pow(2).sum() + model(2 * x).sum()).backward()
+  red.finish()
+  assert red.n_launched_total == n_before + len(red.buckets)
   avg = flat.g.clone() * red.grad_scale
   # single-process reference on the concatenated batch
   ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
