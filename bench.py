@@ -393,6 +393,165 @@ def in_step_times(trainer, it, timers, ops, sets=6):
   return {"fwd_ms": mean(pick(0)), "bwd_data_ms": mean(pick(1)), "wgrad_ms": mean(pick(2)), "ops_timed": len(ops), "iterations": sets}
 
 
+def family_table(trainer, it, timers, batch, device, sets=6, layer_times_path=None):
+  """families[] of the bench line: what every family of launches costs INSIDE the training step,
+  next to its algorithmic work and the peak that bounds it.
+
+  How: pcmi_net_time_all -- HIP events around every op of the executor's program on the stream it runs on (forward and
+  backward launches on the compute stream, weight gradients on the side stream; the grouped coarse-level launches as
+  launches) over `sets` further iterations with nothing synchronised in between, the launch count of every call from the
+  library's own counter -- plus torch events around the three phases outside the executor: batch preparation (planning
+  stream: uploads, coordinate hash, strided levels, kernel maps, mask sort, pair selection), the loss block (pair gathers,
+  PointInfoNCE forward + backward, gradient scatter) and the SGD step.  `ms` is stream time between the two events of a
+  call, i.e. kernels + the gaps between them + waiting for compute units beside the other streams -- what the call costs
+  where it runs, not its stand-alone kernel time.  Work: exact pair counts of the step's own kernel maps (the pair as one
+  two-segment tensor); conv flops = 2 M cin cout per launch kind, bytes = SURVEY 8d's formula; BatchNorm 12 / 20 B per
+  element forward / backward."""
+  import torch
+  import pointcontrast_amd.minkowski as ME
+  eng = trainer.engine
+  ops, tens = eng._ops, eng._tensors
+  # --- exact pair counts / rows of the step's tensors (the same coordinates the step plans)
+  st = level1_tensor(batch, device, joint=True)
+  cm = st.coords_man
+  keys, rows = [st.coords_key], [st.F.shape[0]]
+  for _ in range(eng.n_down):
+    keys.append(cm.stride(keys[-1], 2))
+    rows.append(int(cm.size(keys[-1])))
+  work = []
+  for o in ops:
+    li, lo = tens[o["in_"]]["level"], tens[o["out"]]["level"]
+    if o["type"] != 0:
+      work.append(dict(M=0, n_in=rows[li], n_out=rows[lo], K=0))
+      continue
+    ks = o["kernel_size"]
+    if ks == 1:
+      M, K = rows[li], 1
+    else:
+      m = cm.kernel_map(keys[lo], keys[li], ks, o["stride"], o["region"]) if o["transpose"] else cm.kernel_map(keys[li], keys[lo], ks, o["stride"], o["region"])
+      M, K = int(m.M), ks ** 3
+    work.append(dict(M=M, n_in=rows[li], n_out=rows[lo], K=K))
+  # --- events outside the executor
+  marks = {"plan": [], "loss": [], "sgd": []}
+  plan_stream = ME.handle_pool.plan_stream(device)
+  orig_prepare, orig_fwd, orig_bwd, orig_step = trainer._prepare, eng.forward, eng.backward, trainer.optimizer.step
+  ev = lambda: torch.cuda.Event(enable_timing=True)
+
+  def prepare(*a, **k):
+    e0, e1 = ev(), ev()
+    e0.record(plan_stream)
+    r = orig_prepare(*a, **k)
+    e1.record(plan_stream)
+    marks["plan"].append((e0, e1))
+    return r
+
+  pending = {}
+
+  def forward(*a, **k):
+    r = orig_fwd(*a, **k)
+    pending["e0"] = ev()
+    pending["e0"].record()
+    return r
+
+  def backward(*a, **k):
+    e1 = ev()
+    e1.record()
+    marks["loss"].append((pending.pop("e0"), e1))
+    return orig_bwd(*a, **k)
+
+  def step(*a, **k):
+    e0, e1 = ev(), ev()
+    e0.record()
+    r = orig_step(*a, **k)
+    e1.record()
+    marks["sgd"].append((e0, e1))
+    return r
+
+  trainer._prepare, eng.forward, eng.backward, trainer.optimizer.step = prepare, forward, backward, step
+  try:
+    eng.time_all(sets)
+    for _ in range(sets):
+      trainer._train_iter(it, timers)
+    torch.cuda.synchronize()
+    recs, groups, counts = eng.timed_ms(sets), eng.timed_groups_ms(sets), eng.timed_launches(sets)
+  finally:
+    trainer._prepare, eng.forward, eng.backward, trainer.optimizer.step = orig_prepare, orig_fwd, orig_bwd, orig_step
+    eng.time_all(0)
+  n = len(ops)
+  mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
+  per_op = []
+  for q in range(n):
+    per_op.append(tuple(mean([r[kind][q] for r in recs if r[kind][q] >= 0]) for kind in range(3)) +
+                  tuple(mean([c[kind][q] for c in counts]) for kind in range(3)))
+  grp_ms, grp_n = mean([sum(g) for g in groups]), mean([sum(c[3]) for c in counts])
+  names = {off: nme[:-len(".kernel")] for (nme, prm), off in zip(trainer.model.named_parameters(), trainer.flat.offsets) if nme.endswith(".kernel")}
+  if layer_times_path:
+    with open(layer_times_path, "w") as f:
+      f.write("op\tlayer\ttype\tK\tcin\tcout\trows_in\trows_out\tpairs\tgflop_per_launch\tfwd_ms\tbwd_ms\twgrad_ms\tfwd_launches\tbwd_launches\twgrad_launches\n")
+      for q, (o, w) in enumerate(zip(ops, work)):
+        t = per_op[q]
+        f.write("%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%.4f\t%.4f\t%.4f\t%.4f\t%.1f\t%.1f\t%.1f\n" % (
+            q, names.get(o.get("w_off"), "-") if o["type"] == 0 else "-", ("conv", "bn", "l2norm")[o["type"]], w["K"], o.get("cin", 0),
+            o.get("cout", 0), w["n_in"], w["n_out"], w["M"], 2e-9 * w["M"] * o.get("cin", 0) * o.get("cout", 0), t[0], t[1], t[2], t[3], t[4], t[5]))
+      f.write("# grouped coarse-level weight gradients: %.4f ms, %.1f launches per step (timed as launches, not per layer: wgrad_ms 0 above)\n" % (grp_ms, grp_n))
+  fam = {}
+
+  def add(key, ms, launches, gflop=0.0, gb=0.0):
+    d = fam.setdefault(key, dict(ms=0.0, launches=0.0, gflop=0.0, gb=0.0))
+    d["ms"] += ms
+    d["launches"] += launches
+    d["gflop"] += gflop
+    d["gb"] += gb
+
+  for q, (o, w) in enumerate(zip(ops, work)):
+    f_ms, b_ms, w_ms, f_n, b_n, w_n = per_op[q]
+    if o["type"] == 0:
+      cin, cout = o["cin"], o["cout"]
+      fl = 2e-9 * w["M"] * cin * cout
+      by_f = 1e-9 * (w["M"] * (4 * cin + 8) + w["n_out"] * 4 * cout + 4 * w["K"] * cin * cout)
+      by_b = 1e-9 * (w["M"] * (4 * cout + 8) + w["n_in"] * 4 * cin + 4 * w["K"] * cin * cout)
+      by_w = 1e-9 * (w["M"] * 4 * (cin + cout) + 8 * w["M"] + 4 * w["K"] * cin * cout)
+      lvl1 = min(tens[o["in_"]]["level"], tens[o["out"]]["level"]) == 0
+      key = "conv level 1 (fwd + bwd-data; stem, 2^3 down / up, block8, head)" if lvl1 else "conv coarse (strides 2-16, fwd + bwd-data, incl. split-reduce / fix-up launches)"
+      has_b = b_n > 0
+      add(key, f_ms + b_ms, f_n + b_n, fl * (2 if has_b else 1), by_f + (by_b if has_b else 0.0))
+      add("weight gradients (side stream; incl. slab sums / reductions)", w_ms, w_n, fl, by_w)
+    elif o["type"] == 1:
+      e = 1e-9 * w["n_in"] * o["cout"]
+      add("BatchNorm forward (statistics + merge + apply, +ReLU / +residual)", f_ms, f_n, 0.0, 12 * e)
+      add("BatchNorm backward (statistics + merge + apply)", b_ms, b_n, 0.0, 20 * e)
+    else:
+      e = 1e-9 * w["n_in"] * o["cout"]
+      add("L2 normalisation (fwd + bwd)", f_ms + b_ms, f_n + b_n, 0.0, (8 + 16) * e)
+  add("weight gradients (side stream; incl. slab sums / reductions)", grp_ms, grp_n)
+  el = lambda key: mean([a.elapsed_time(b) for a, b in marks[key][1:]])  # (the first iteration's events predate time_all's sync)
+  npar = trainer.flat.numel
+  out = []
+  peak6 = PEAK_BF16_MFMA_TFLOPS / 6
+  for key, d in fam.items():
+    ent = {"family": key, "ms_per_step": round(d["ms"], 4), "launches_per_step": round(d["launches"], 1)}
+    if d["gflop"] > 0:
+      ent.update(gflop=round(d["gflop"], 2), achieved_tflops=round(d["gflop"] * 1e-3 / (d["ms"] * 1e-3), 2) if d["ms"] > 0 else None,
+                 peak_tflops=round(peak6, 1), bound="mfma (six-product split arithmetic; the 32-channel layers of the family are HBM-bound and counted by time)",
+                 algo_gb=round(d["gb"], 3))
+      ent["frac"] = round(ent["achieved_tflops"] / peak6, 4) if ent["achieved_tflops"] else None
+    else:
+      ent.update(algo_gb=round(d["gb"], 3), achieved_gbs=round(d["gb"] / (d["ms"] * 1e-3), 1) if d["ms"] > 0 else None, peak_gbs=PEAK_HBM_GBS, bound="hbm")
+      ent["frac"] = round(ent["achieved_gbs"] / PEAK_HBM_GBS, 4) if ent["achieved_gbs"] else None
+    out.append(ent)
+  out.append({"family": "batch preparation (planning stream: upload, hash, levels, kernel maps, mask sort, pair selection)",
+              "ms_per_step": round(el("plan"), 4), "bound": "latency (integer / index work, off the chain)"})
+  out.append({"family": "loss block (pair gathers, PointInfoNCE fwd + bwd, gradient scatter)", "ms_per_step": round(el("loss"), 4),
+              "gflop": round(5 * 2 * 4096 * 4096 * 32 * 1e-9, 3), "bound": "latency (4096 x 4096 x 32: 13 us at the six-product bound)"})
+  sgd_ms = el("sgd")
+  out.append({"family": "SGD step (one launch over the flat buffers)", "ms_per_step": round(sgd_ms, 4), "launches_per_step": 1,
+              "algo_gb": round(npar * 20e-9, 3), "achieved_gbs": round(npar * 20e-9 / (sgd_ms * 1e-3), 1) if sgd_ms > 0 else None,
+              "peak_gbs": PEAK_HBM_GBS, "bound": "hbm", "frac": round(npar * 20e-9 / (sgd_ms * 1e-3) / PEAK_HBM_GBS, 4) if sgd_ms > 0 else None})
+  return {"note": "in-step stream time per family, mean over %d iterations (HIP events on the streams the launches run on; the families "
+                  "of the compute stream add up to the chain, the weight gradients run beside it on the side stream)" % sets,
+          "families": out}
+
+
 def fp32_instruction_leg(args, steps=10, warmup=5, limit_s=240):
   """The same iteration with every split-precision kernel switched off (PCMI_CONV16_X3=0 PCMI_WGRAD_X3T=0 PCMI_NCE_X3=0:
   the fp32 MFMA instruction throughout -- literally the reference's arithmetic), in a child process of this run."""
@@ -497,7 +656,21 @@ def main():
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
   loss_val = float(res["loss"])
+  per_rank = None
   if world > 1:
+    # what every rank saw: its own wall time of the K steps, its host-side enqueue time and how long its all-reduces stayed
+    # exposed after its backward pass -- so that the first real N > 1 run says WHICH rank everyone waited for (the ranks'
+    # batches differ by +-10 % in voxel count; GradReducer.finish() makes every step as long as the slowest rank's)
+    try:
+      rep = trainer.reducer.overlap_report(skip_steps=args.warmup) or {}
+    except Exception:  # noqa: BLE001  (measurement garnish: every rank must still reach the collectives below)
+      rep = {}
+    mine = torch.tensor([elapsed, host_enqueue, float(rep.get("exposed_after_backward_ms") or 0.0),
+                         float(batch["sinput0_C"].shape[0] + batch["sinput1_C"].shape[0])], device=device, dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    per_rank = [{"rank": r, "ms_per_step": round(float(t[0]) / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(float(t[1]) / args.steps * 1e3, 3),
+                 "exposed_after_backward_ms": round(float(t[2]), 3), "voxels_per_pass": int(t[3])} for r, t in enumerate(allr)]
     tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
@@ -543,7 +716,10 @@ def main():
                                    "buckets": len(trainer.reducer.buckets),
                                    "bucket_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in trainer.reducer.buckets],
                                    "rccl_max_channels": du.rccl_channel_cap(),
-                                   "overlap": trainer.reducer.overlap_report(skip_steps=args.warmup)}
+                                   "overlap": trainer.reducer.overlap_report(skip_steps=args.warmup),
+                                   "per_rank": per_rank,
+                                   "step_skew_ms": (round(max(p_["ms_per_step"] for p_ in per_rank) - min(p_["ms_per_step"] for p_ in per_rank), 3)
+                                                    if per_rank else None)}
                                   if (world > 1 or forced) else None)},
     }
     if args.layer_table:
@@ -564,6 +740,14 @@ def main():
           except Exception as e:  # measurement garnish: never lose the headline to it
             instep = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
           log("in-step kernel times: %s" % instep)
+        if cfg.misc.get("joint_pair", True) and args.engine == "native":
+          try:
+            ft = family_table(trainer, it, timers, batch, device,
+                              layer_times_path=(args.layer_table + ".times.tsv") if args.layer_table else None)
+            out["families"], out["families_note"] = ft["families"], ft["note"]
+          except Exception as e:  # measurement garnish: never lose the headline to it
+            out["families"], out["families_note"] = None, "%s: %s" % (type(e).__name__, str(e)[:300])
+          log("families done")
       dom, kernels = kernel_rooflines(batch, device, joint=bool(cfg.misc.get("joint_pair", True)) and args.engine == "native")
       log("rooflines done")
       # Which kernel is "the dominant one": launches per step of a shape (from the lowered program) x its stand-alone

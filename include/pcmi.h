@@ -414,13 +414,23 @@ int pcmi_net_export_tensor(pcmi_net_t* net, int pass, int tensor, int64_t* rows,
 int pcmi_net_memory_bytes(pcmi_net_t* net, size_t* bytes);
 /* Measurement (bench.py roofline.in_step_ms; the reference has no counterpart: torch.autograd.profiler would be its
  * tool): timing events around the convolution launches of the ops `ops[0..n_ops)` (indices into the program) INSIDE the
- * passes -- forward, the backward-data launch and (on the executor's weight-gradient stream) the weight-gradient launch
- * of the same op -- in a ring of n_sets event sets, one per forward pass enqueued after this call (networks run as one
+ * passes -- forward, the backward(-data) launch and (on the executor's weight-gradient stream) the weight-gradient launch
+ * of the same op; any op type -- in a ring of n_sets event sets, one per forward pass enqueued after this call (networks run as one
  * pass per iteration; the backward pass records into the set of the forward before it).  n_ops == 0 stops timing.
  * Synchronises the device.  pcmi_net_timed_ms waits for set `set` and returns the elapsed stream time per op in ms
  * (-1: not recorded). */
 int pcmi_net_time_ops(pcmi_net_t* net, const int* ops, int n_ops, int n_sets);
 int pcmi_net_timed_ms(pcmi_net_t* net, int set, float* fwd_ms, float* bwd_ms, float* wgrad_ms, int n_ops);
+/* The same for EVERY op of the program (convolutions, BatchNorms, the L2 normalisation: forward and backward launches on
+ * the pass's stream, weight gradients on the executor's side stream) -- bench.py's per-layer times and `families[]`.  The
+ * weight gradients the executor collects into grouped launches (coarse levels) stay grouped; those launches are timed as
+ * such: pcmi_net_timed_groups_ms returns up to `cap` of them for set `set` (n_out = how many).  n_sets == 0 stops timing.
+ * pcmi_net_timed_ms then takes n_ops = the number of ops of the program. */
+int pcmi_net_time_all(pcmi_net_t* net, int n_sets);
+int pcmi_net_timed_groups_ms(pcmi_net_t* net, int set, float* ms, int cap, int* n_out);
+/* Kernel launches each timed call of set `set` enqueued (forward, backward(-data), weight gradient; 0 = not recorded), and
+ * -- groups != NULL after pcmi_net_time_all -- of its first groups_cap grouped weight-gradient launches. */
+int pcmi_net_timed_launches(pcmi_net_t* net, int set, int* fwd, int* bwd, int* wgrad, int n_ops, int* groups, int groups_cap);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,10 @@ PROTOTYPES = {
     "pcmi_net_memory_bytes": (C.c_int, [c_vp, C.POINTER(c_sz)]),
     "pcmi_net_time_ops": (C.c_int, [c_vp, C.POINTER(C.c_int), C.c_int, C.c_int]),
     "pcmi_net_timed_ms": (C.c_int, [c_vp, C.c_int, C.POINTER(c_f32), C.POINTER(c_f32), C.POINTER(c_f32), C.c_int]),
+    "pcmi_net_time_all": (C.c_int, [c_vp, C.c_int]),
+    "pcmi_net_timed_launches": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int,
+                                          C.POINTER(C.c_int), C.c_int]),
+    "pcmi_net_timed_groups_ms": (C.c_int, [c_vp, C.c_int, C.POINTER(c_f32), C.c_int, C.POINTER(C.c_int)]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -28,7 +28,14 @@ void set_error(const char* fmt, ...);
     }                                  \
   } while (0)
 
-#define PCMI_LAUNCH_CHECK() PCMI_HIP_CHECK(hipGetLastError())
+// kernel launches of the calling thread so far (every launch site ends in PCMI_LAUNCH_CHECK): what the executor's timing
+// mode reads before and after an op to report launches per op (pcmi_net_timed_launches)
+extern thread_local long g_launches;
+#define PCMI_LAUNCH_CHECK()         \
+  do {                              \
+    ++pcmi::g_launches;             \
+    PCMI_HIP_CHECK(hipGetLastError()); \
+  } while (0)
 
 static inline hipStream_t as_stream(pcmi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -23,6 +23,8 @@ namespace pcmi {
 // error string (thread local)
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+thread_local long g_launches = 0;
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

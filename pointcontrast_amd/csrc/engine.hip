@@ -213,6 +213,14 @@ struct pcmi_net {
   std::vector<hipEvent_t> timed_ev;  // [set][timed op][forward begin / end, backward-data begin / end, weight-gradient begin / end (side stream)]
   std::vector<char> timed_hit;       // [set][timed op]: bit 0 forward, bit 1 backward-data, bit 2 weight gradient recorded
   int timed_sets = 0, timed_cur = -1;
+  // pcmi_net_time_all: EVERY op is timed and the coarse-level weight gradients stay grouped (a timed op is otherwise launched
+  // on its own); the grouped launches get events of their own: [set][flush][begin / end], timed_group_n[set] of them recorded
+  static constexpr int kTimedGroups = 16;
+  bool timed_keep_groups = false;
+  std::vector<hipEvent_t> timed_group_ev;
+  std::vector<int> timed_group_n;
+  std::vector<int> timed_cnt;        // [set][timed op][forward / backward / weight gradient]: kernel launches of that call
+  std::vector<int> timed_group_cnt;  // [set][flush]
   int timed_slot(int op) const {     // index into timed_hit (x kTimedEv: into timed_ev) of `op` in the current set, or -1
     if (timed_ops.empty() || timed_cur < 0) return -1;
     for (size_t q = 0; q < timed_ops.size(); ++q)
@@ -221,6 +229,12 @@ struct pcmi_net {
   }
   void timed_clear() {
     for (hipEvent_t e : timed_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : timed_group_ev) (void)hipEventDestroy(e);
+    timed_group_ev.clear();
+    timed_group_n.clear();
+    timed_cnt.clear();
+    timed_group_cnt.clear();
+    timed_keep_groups = false;
     timed_ev.clear();
     timed_ops.clear();
     timed_hit.clear();
@@ -506,7 +520,20 @@ struct BackwardRun {
     PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
     PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
     pending[0] = used[0] = true;
-    return wgrad_group_flush(n.wgroup, n.side[0]);
+    int slot = -1;  // (pcmi_net_time_all: the grouped launch between two events of the current set)
+    if (n.timed_keep_groups && n.timed_cur >= 0) {
+      const int set = n.timed_cur % n.timed_sets;
+      if (n.timed_group_n[set] < pcmi_net::kTimedGroups) slot = set * pcmi_net::kTimedGroups + n.timed_group_n[set];
+    }
+    if (slot >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_group_ev[2 * slot], n.side[0]));
+    const long l0 = g_launches;
+    const int rc = wgrad_group_flush(n.wgroup, n.side[0]);
+    if (slot >= 0 && !rc) {
+      n.timed_group_cnt[slot] = (int)(g_launches - l0);
+      PCMI_HIP_CHECK(hipEventRecord(n.timed_group_ev[2 * slot + 1], n.side[0]));
+      ++n.timed_group_n[n.timed_cur % n.timed_sets];
+    }
+    return rc;
   }
   int bucket_of(int64_t offp) const {
     int b = 0;
@@ -607,7 +634,7 @@ struct BackwardRun {
       // (profiles/r06a_*: the bound of moving the level-1 weight gradients out of the backward pass)
       const long skip_rows = debug_env_long("PCMI_DEBUG_SKIP_WGRAD_ROWS");
       const bool skip_wgrad = skip_rows > 0 && std::min(n_in, n_out) >= skip_rows && op.in != n.input_tensor;
-      if (!skip_wgrad && !two_sides && !op.transpose && op.kernel_size == 3 && op.stride == 1 && !op.has_bias && map && n.timed_slot(i) < 0) {
+      if (!skip_wgrad && !two_sides && !op.transpose && op.kernel_size == 3 && op.stride == 1 && !op.has_bias && map && (n.timed_keep_groups || n.timed_slot(i) < 0)) {
         grouped = wgrad_group_add(n.wgroup, x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, grads + op.w_off, 1, n.side[0]);
         if (!grouped && wgrad_group_size(n.wgroup) > 0) {  // another tile shape, or the group is full: launch it, start a new one
           rc = flush_group();
@@ -635,26 +662,33 @@ struct BackwardRun {
       }
       const int tw = n.timed_slot(i);
       if (tw >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tw + 4], wst));
+      const long lw0 = g_launches;
       rc = spconv_backward_weight(x.p, x.ld, n_in, op.cin, dy.p, dy.ld, n_out, op.cout, map, op.transpose, grads + op.w_off,
                                   op.has_bias ? grads + op.b_off : nullptr, 1, wws->p, wws->cap, wst);
       if (rc) return rc;
       if (tw >= 0) {
         PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tw + 5], wst));
         n.timed_hit[tw] |= 4;
+        n.timed_cnt[3 * tw + 2] = (int)(g_launches - lw0);
       }
       }  // !grouped
       if (op.in != n.input_tensor) {
         const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
         const int tq = n.timed_slot(i);
         if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 2], st));
+        const long lb0 = g_launches;
         rc = spconv_backward_data(dy.p, dy.ld, n_out, op.cout, params + op.w_off, op.cin, map, op.transpose, dx.p, dx.ld,
                                   n_in, pl.acc_in, ps->ws.p, ps->ws.cap, st);
         if (tq >= 0 && !rc) {
           PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 3], st));
           n.timed_hit[tq] |= 2;
+          n.timed_cnt[3 * tq + 1] = (int)(g_launches - lb0);
         }
       }
     } else if (op.type == PCMI_OP_BN) {
+      const int tb = n.timed_slot(i);
+      if (tb >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tb + 2], st));
+      const long lb0 = g_launches;
       const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
       View dr = {nullptr, 0};
       if (op.in2 >= 0) dr = grad_view(n, *ps, op.in2, d_out, d_ld);
@@ -676,10 +710,23 @@ struct BackwardRun {
         rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats0,
                          stats0 + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, scratch_g + op.cout,
                          grads + op.w_off, grads + op.b_off, ps->ws.p, ps->ws.cap, st);
+      if (tb >= 0 && !rc) {
+        PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tb + 3], st));
+        n.timed_hit[tb] |= 2;
+        n.timed_cnt[3 * tb + 1] = (int)(g_launches - lb0);
+      }
     } else {
       const View dx = grad_view(n, *ps, op.in, d_out, d_ld);
+      const int tl = n.timed_slot(i);
+      if (tl >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tl + 2], st));
+      const long ll0 = g_launches;
       rc = pcmi_l2norm_bwd(dy.p, dy.ld, y.p, y.ld, (const float*)(ps->act.p + ps->stat_off[i]), n_in, op.cout, dx.p, dx.ld,
                            (pcmi_stream_t)st);
+      if (tl >= 0 && !rc) {
+        PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tl + 3], st));
+        n.timed_hit[tl] |= 2;
+        n.timed_cnt[3 * tl + 1] = (int)(g_launches - ll0);
+      }
     }
     if (rc) return rc;
     // A bucket is final once this op's kernels have run -- on `st` AND, for the weight gradients, on the side stream.
@@ -1031,22 +1078,20 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     ++n.timed_cur;
     const size_t per = n.timed_ops.size(), base = (size_t)(n.timed_cur % n.timed_sets) * per;
     for (size_t q = 0; q < per; ++q) n.timed_hit[base + q] = 0;
+    if (n.timed_keep_groups) n.timed_group_n[n.timed_cur % n.timed_sets] = 0;
   }
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
     const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
     if (i == late_first_op) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));  // (PCMI_DEBUG_LATE_WGRAD)
+    const int tq = n.timed_slot(i);
+    if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 0], st));
+    const long lf0 = g_launches;
     if (op.type == PCMI_OP_CONV) {
-      const int tq = n.timed_slot(i);
-      if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 0], st));
       rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
                           op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, ps.ws.p, ps.ws.cap,
                           st);
-      if (tq >= 0 && !rc) {
-        PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 1], st));
-        n.timed_hit[tq] |= 1;
-      }
     } else if (op.type == PCMI_OP_BN) {
       View r = {nullptr, 0};
       if (op.in2 >= 0) r = act_view(n, ps, op.in2);
@@ -1077,6 +1122,11 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), stream);
     }
     if (rc) return rc;
+    if (tq >= 0) {
+      PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 1], st));
+      n.timed_hit[tq] |= 1;
+      n.timed_cnt[3 * tq + 0] = (int)(g_launches - lf0);
+    }
     if (i == pack_bwd_at) {  // the side stream starts behind this point of the pass (and behind the job table's upload)
       PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
       PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
@@ -1116,22 +1166,68 @@ int pcmi_net_stream_wait_bucket(pcmi_net_t* net, pcmi_stream_t stream) {
 }
 
 int pcmi_net_time_ops(pcmi_net_t* net, const int* ops, int n_ops, int n_sets) {
-  PCMI_REQUIRE(net && (n_ops == 0 || (ops && n_sets > 0)) && n_ops >= 0 && n_ops <= 64 && n_sets <= 64, PCMI_ERR_INVALID,
+  PCMI_REQUIRE(net && (n_ops == 0 || (ops && n_sets > 0)) && n_ops >= 0 && n_ops <= 1024 && n_sets <= 64, PCMI_ERR_INVALID,
                "net_time_ops: bad argument");
   PCMI_HIP_CHECK(hipDeviceSynchronize());  // nothing in flight records into the events that go away
   net->timed_clear();
   if (n_ops == 0) return PCMI_OK;
   for (int q = 0; q < n_ops; ++q)
-    PCMI_REQUIRE(ops[q] >= 0 && ops[q] < (int)net->ops.size() && net->ops[ops[q]].type == PCMI_OP_CONV, PCMI_ERR_INVALID,
-                 "net_time_ops: op %d is not a convolution of this network", ops[q]);
+    PCMI_REQUIRE(ops[q] >= 0 && ops[q] < (int)net->ops.size(), PCMI_ERR_INVALID, "net_time_ops: op %d is not an op of this network", ops[q]);
   net->timed_ops.assign(ops, ops + n_ops);
   net->timed_sets = n_sets;
   net->timed_hit.assign((size_t)n_sets * n_ops, 0);
+  net->timed_cnt.assign((size_t)3 * n_sets * n_ops, 0);
   for (int e = 0; e < pcmi_net::kTimedEv * n_sets * n_ops; ++e) {
     hipEvent_t ev = nullptr;
     PCMI_HIP_CHECK(hipEventCreate(&ev));
     net->timed_ev.push_back(ev);
   }
+  return PCMI_OK;
+}
+
+int pcmi_net_time_all(pcmi_net_t* net, int n_sets) {
+  PCMI_REQUIRE(net && n_sets >= 0 && n_sets <= 64, PCMI_ERR_INVALID, "net_time_all: bad argument");
+  if (n_sets == 0) return pcmi_net_time_ops(net, nullptr, 0, 0);
+  std::vector<int> all(net->ops.size());
+  for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
+  const int rc = pcmi_net_time_ops(net, all.data(), (int)all.size(), n_sets);
+  if (rc) return rc;
+  net->timed_keep_groups = true;
+  net->timed_group_n.assign(n_sets, 0);
+  net->timed_group_cnt.assign((size_t)pcmi_net::kTimedGroups * n_sets, 0);
+  for (int e = 0; e < 2 * pcmi_net::kTimedGroups * n_sets; ++e) {
+    hipEvent_t ev = nullptr;
+    PCMI_HIP_CHECK(hipEventCreate(&ev));
+    net->timed_group_ev.push_back(ev);
+  }
+  return PCMI_OK;
+}
+
+int pcmi_net_timed_groups_ms(pcmi_net_t* net, int set, float* ms, int cap, int* n_out) {
+  PCMI_REQUIRE(net && ms && n_out && cap >= 0 && net->timed_keep_groups && set >= 0 && set < net->timed_sets, PCMI_ERR_INVALID,
+               "net_timed_groups_ms: bad argument (or pcmi_net_time_all is not active)");
+  const int n = std::min(cap, net->timed_group_n[set]);
+  for (int g = 0; g < n; ++g) {
+    const int slot = set * pcmi_net::kTimedGroups + g;
+    PCMI_HIP_CHECK(hipEventSynchronize(net->timed_group_ev[2 * slot + 1]));
+    PCMI_HIP_CHECK(hipEventElapsedTime(&ms[g], net->timed_group_ev[2 * slot], net->timed_group_ev[2 * slot + 1]));
+  }
+  *n_out = n;
+  return PCMI_OK;
+}
+
+int pcmi_net_timed_launches(pcmi_net_t* net, int set, int* fwd, int* bwd, int* wgrad, int n_ops, int* groups, int groups_cap) {
+  PCMI_REQUIRE(net && fwd && bwd && wgrad && n_ops == (int)net->timed_ops.size() && set >= 0 && set < net->timed_sets,
+               PCMI_ERR_INVALID, "net_timed_launches: bad argument");
+  for (int q = 0; q < n_ops; ++q) {
+    const size_t h = (size_t)set * n_ops + q;
+    fwd[q] = (net->timed_hit[h] & 1) ? net->timed_cnt[3 * h + 0] : 0;
+    bwd[q] = (net->timed_hit[h] & 2) ? net->timed_cnt[3 * h + 1] : 0;
+    wgrad[q] = (net->timed_hit[h] & 4) ? net->timed_cnt[3 * h + 2] : 0;
+  }
+  if (groups && net->timed_keep_groups)
+    for (int g = 0; g < groups_cap; ++g)
+      groups[g] = g < net->timed_group_n[set] ? net->timed_group_cnt[(size_t)set * pcmi_net::kTimedGroups + g] : 0;
   return PCMI_OK;
 }
 

@@ -29,6 +29,7 @@
 //   tiles (+ optional split of the offset range over blockIdx.z into a partial buffer) so
 //   that the small, wide levels still fill 256 CUs.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "common.h"
@@ -840,29 +841,8 @@ static bool sk_rows_eligible(int64_t rows, int K) {
   const int64_t mt = sk_min_tiles();
   return K > 1 && mt > 0 && rows >= 4096 /* kSortRowsMin: such maps carry tile units */ && ceil_div(rows, 128) >= mt;
 }
-// PCMI_SK_MID=<tiles>: the unit-balanced launch ALSO for the levels whose whole-tile launch would split its offsets over
-// blockIdx.z (ksplit > 1: fewer tiles than 2.5 workgroups per compute unit), from <tiles> 128-row tiles up (0 = off).
-// There the offset split gives every blockIdx.z the same NUMBER of offsets whatever their occupancy, rounds the grid to
-// whole residency rounds and leaves ksplit full-size partial tensors to split_reduce_kernel; the unit-balanced launch
-// gives every workgroup the same number of occupied (tile, offset, chunk) steps and only the tiles shared between
-// workgroups go through partial slots (sk_fixup_kernel).  PCMI_SK_MID_STEPS: chunk steps a workgroup should get at least
-// (the grid shrinks below the resident maximum when a level has fewer).  Read per call.
-static int64_t sk_mid_tiles() {
-  const char* e = getenv("PCMI_SK_MID");
-  return e ? (int64_t)atoll(e) : 0;
-}
-static bool sk_mid_eligible(int64_t rows, int K) {
-  const int64_t mt = sk_mid_tiles();
-  return K > 1 && mt > 0 && rows >= 4096 && ceil_div(rows, 128) >= mt;
-}
-static int sk_mid_grid(int G_max, int64_t n_tiles, int K, int nch) {
-  const char* e = getenv("PCMI_SK_MID_STEPS");
-  const int64_t steps = std::max<int64_t>(1, e ? atoll(e) : 16);
-  const int64_t want = ceil_div(n_tiles * K * nch, steps);
-  return (int)std::max<int64_t>(8, std::min<int64_t>(G_max, ceil_div(want, 8) * 8));
-}
 static size_t sk_partial_bytes(int64_t rows, int N, int K) {
-  return (sk_rows_eligible(rows, K) || sk_mid_eligible(rows, K)) ? (size_t)sk_workgroups_max() * 2 * 128 * N * sizeof(float) : 0;
+  return sk_rows_eligible(rows, K) ? (size_t)sk_workgroups_max() * 2 * 128 * N * sizeof(float) : 0;
 }
 
 // The 16-row kernels take the 128-row tiles of levels with at least PCMI_CONV16 rows (0 = never, 1 = always).  Default
@@ -953,7 +933,8 @@ constexpr int kMaxKSplit = 27;
 // blockIdx.z into partial sums instead.
 // wide: the contraction has >= 64 channels (with N >= 64 the launch can take the split-precision kernel, whose slices
 // are at least 64 wide)
-static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false) {
+// C: the contraction size when the caller knows it (0: the round-2 rule alone)
+static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false, int C = 0) {
   Plan p;
   const int nt_all = N / 32;
   p.NT = nt_all % 4 == 0 ? 4 : (nt_all % 3 == 0 ? 3 : (nt_all % 2 == 0 ? 2 : 1));
@@ -973,13 +954,40 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false) 
     // 4.0 -> 244.6 pairs/s, profiles/r03h_bench_ab_*.txt)
     const int64_t target = (25 * (int64_t)num_cu()) / 10;
     if (wgs < target) p.ksplit = (int)std::min<int64_t>(std::min<int64_t>(K, kMaxKSplit), ceil_div(target, wgs));
+    // Round 6: the split by RESIDENCY ROUNDS, for the launches of the 16-row split-precision kernel (whose residency is
+    // known: x3_workgroups).  The kernel's run time is that of its longest workgroup chain: rounds x (offsets per workgroup
+    // x chunks + a fixed share), and "2.5 workgroups per CU" ignores both factors -- on the bench batch it gives the
+    // stride-16 level (28 workgroups per split) ksplit 23, i.e. 4 of the 23 z-slices carry TWO offsets and every launch
+    // takes 16 chunk steps where ksplit 27 takes 8; the stride-2 level (316 tiles) ksplit 3 = 948 workgroups on 768
+    // slots, a full round of 27 steps and a quarter-filled second one, where ksplit 2 is ONE round of 42 steps and a
+    // third less partial traffic; the stride-4 128-channel launches 711 workgroups on 512 slots.  cost(ks), in chunk
+    // steps: rounds x (ceil(K / ks) C / 32 + 3) x (a penalty under 2 workgroups per CU: nobody hides a step's latency)
+    // + the partial tensors' write + read-back (8 B per element and split at ~3 TB/s against ~2 us per step).  Taken only
+    // when it beats the rule above by 10 % of its own estimate.  PCMI_KSPLIT_RULE=0: the rule above alone (read per call).
+    const char* re = getenv("PCMI_KSPLIT_RULE");
+    if (C >= 64 && wide && p.RW == 4 && wgs < target && !(re && re[0] == '0') && conv16_x3(p.NT, C, N) && min16 > 0 && rows >= min16) {
+      const double slots = (double)x3_workgroups(p.NT), nch = (double)(C / kKC);
+      const double traffic = (double)rows * N * 8.0 / 3.0e6 / 2.0;  // chunk steps per partial tensor
+      auto cost = [&](int ks) {
+        const double w = (double)wgs * ks;
+        const double rounds = std::ceil(w / slots);
+        const double thin = std::max(1.0, 2.0 * num_cu() / std::min(w, slots));
+        return rounds * ((double)ceil_div((int64_t)K, (int64_t)ks) * nch + 3.0) * thin + traffic * ks;
+      };
+      int best = p.ksplit;
+      const int kmax = (int)std::min<int64_t>(K, kMaxKSplit);
+      for (int ks = 1; ks <= kmax; ++ks)
+        if (cost(ks) < cost(best) - 1e-9) best = ks;
+      if (cost(best) < 0.9 * cost(p.ksplit)) p.ksplit = best;
+    }
   }
   return p;
 }
 
 static size_t partial_bytes(int64_t rows, int N, int K) {
   if (K <= 1 || rows <= 0 || N % 32 != 0) return 0;
-  const int ks = std::max(make_plan(rows, N, K, false, false).ksplit, make_plan(rows, N, K, false, true).ksplit);
+  int ks = std::max(make_plan(rows, N, K, false, false).ksplit, make_plan(rows, N, K, false, true).ksplit);
+  for (int C = 64; C <= 512; C += 32) ks = std::max(ks, make_plan(rows, N, K, false, true, C).ksplit);  // (any contraction size)
   return ks > 1 ? (size_t)ks * rows * N * sizeof(float) : 0;
 }
 
@@ -1062,16 +1070,17 @@ static int run_gathered(const float* x, int64_t x_ld, int64_t x_rows, int C, con
   }
   // 32 -> 32 channels: all weight slices resident in LDS, a wave per 16-row group (spconv32r.hip)
   if (conv32r_eligible(a, x_rows * x_ld * 4)) return conv32r_launch(w_transposed, a, st);
-  Plan p = make_plan(n_rows, N, a.K, false, C >= 64);
+  Plan p = make_plan(n_rows, N, a.K, false, C >= 64, C);
   // (32-channel convs are HBM/latency-bound: the partial tiles cost them more than the balance gains -- measured)
   // (the unit-balanced launch exists for the 16-row kernels: an operand of >= 2 GiB, which they cannot address, takes the
   //  whole-tile launch of spconv_mfma_kernel below)
-  const bool sk_mid = p.ksplit > 1 && sk_mid_eligible(n_rows, a.K);
-  if (map && map->tile_pref && map->perm && p.RW == 4 && ((p.ksplit == 1 && sk_rows_eligible(n_rows, a.K)) || sk_mid) &&
+  // (Round 6 measured this launch also on the levels that split their offsets over blockIdx.z -- ksplit > 1: the stride-2 level
+  //  of the bench batch, 316 tiles, neutral; the stride-4 level as well, 78 tiles cut into 3-10 pieces each, 0.5 ms per step
+  //  SLOWER: profiles/r06a_wgrad_stream_cost_and_sk_mid_ab.txt.  The offset split + split_reduce_kernel stays there.)
+  if (map && map->tile_pref && map->perm && p.RW == 4 && p.ksplit == 1 && sk_rows_eligible(n_rows, a.K) &&
       map->n_tiles == ceil_div(n_rows, 128) && C >= 64 && N >= 64 && conv16_enabled(n_rows, x_rows * x_ld * 4)) {
     const bool x3 = conv16_x3(p.NT, C, N);
-    int G = x3 ? x3_workgroups(p.NT) : sk_workgroups(p.NT);
-    if (sk_mid) G = sk_mid_grid(G, map->n_tiles, a.K, C / kKC);
+    const int G = x3 ? x3_workgroups(p.NT) : sk_workgroups(p.NT);
     const size_t part = sk_partial_bytes(n_rows, N, a.K);
     const size_t need = part + (x3 ? x3_pack_bytes(a.K, C, N) : 0);
     PCMI_REQUIRE(ws && ws_bytes >= need, PCMI_ERR_WORKSPACE, "spconv: workspace %zu < %zu bytes", ws_bytes, need);

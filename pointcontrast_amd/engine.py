@@ -316,6 +316,32 @@ class NativeEngine:
     self._timed = (list(ops), n_sets)
     check(lib.pcmi_net_time_ops(self._h, arr, len(ops), n_sets))
 
+  def time_all(self, n_sets=8):
+    """Timing events around EVERY op of the program inside the next `n_sets` passes (grouped weight gradients stay grouped
+    and are timed as launches: timed_groups_ms); 0 stops.  See include/pcmi.h (pcmi_net_time_all)."""
+    self._timed = (list(range(self.n_ops)) if n_sets else [], n_sets)
+    check(lib.pcmi_net_time_all(self._h, n_sets))
+
+  def timed_groups_ms(self, n_sets=None):
+    """[[ms of every grouped weight-gradient launch] per recorded set] after time_all."""
+    _, sets = getattr(self, "_timed", ([], 0))
+    out = []
+    for s_ in range(min(n_sets or sets, sets)):
+      ms, n = (C.c_float * 16)(), C.c_int()
+      check(lib.pcmi_net_timed_groups_ms(self._h, s_, ms, 16, C.byref(n)))
+      out.append([ms[i] for i in range(n.value)])
+    return out
+
+  def timed_launches(self, n_sets=None):
+    """[(fwd, bwd, wgrad launches per op, [launches per grouped weight-gradient flush])] of the recorded sets."""
+    ops, sets = getattr(self, "_timed", ([], 0))
+    out = []
+    for s_ in range(min(n_sets or sets, sets)):
+      f, b, w, g = (C.c_int * len(ops))(), (C.c_int * len(ops))(), (C.c_int * len(ops))(), (C.c_int * 16)()
+      check(lib.pcmi_net_timed_launches(self._h, s_, f, b, w, len(ops), g, 16))
+      out.append((list(f), list(b), list(w), [x for x in g if x]))
+    return out
+
   def timed_ms(self, n_sets=None):
     """[(fwd_ms, bwd_data_ms, wgrad_ms) per op] of the first `n_sets` recorded sets (waits for them; -1 = not recorded)."""
     ops, sets = getattr(self, "_timed", ([], 0))

@@ -52,6 +52,34 @@ def test_full_config_gradients_match_oracle(ME):
   assert not bad, "gradient tensors off: %s | worst: %s" % (bad[:6], msg)
 
 
+def test_full_config_hardest_gradients_match_oracle(ME):
+  """configs[2] at full size, GRADIENTS (round 5 compared the losses only; gradients at <= 24 k rows): every parameter-
+  gradient tensor of Res16UNet34C under the HardestContrastive loss -- 4096 positives, 1024 hard-negative candidates per
+  cloud on the B = 4, ~87k-voxel batch -- by the fp64-mask rule of test_full_config_gradients_match_oracle; the negatives
+  the device mines are verified as arg-mins and shared with the oracle (pc/lib/ddp_trainer.py:186-238,278-326)."""
+  report = _network_case(ME, "Res16UNet34C", None, 4, 0, npos=4096, voxel_size=0.025, loss="hardest", n_hard=1024)
+  msg = "; ".join("%s dev=%.2e ref32=%.2e" % (n_, d_, r_) for d_, r_, n_, g_ in report[:6])
+  print("full-size hardest-contrastive worst gradient tensors:", msg)
+  bad = [(n_, d_, r_) for d_, r_, n_, _ in report if d_ > max(10 * r_, 5e-5)]
+  assert not bad, "gradient tensors off: %s | worst: %s" % (bad[:6], msg)
+
+
+def test_1cm_config_gradients_match_oracle(ME):
+  """configs[4] shape, BACKWARD (round 5: forward + loss only): one 1 cm pair -- > 250 k rows over the two clouds, ~15
+  neighbours per voxel at level 1 -- through forward, PointInfoNCE and backward; every parameter-gradient tensor by the
+  fp64-mask rule, the level-1 tensors (whose kernels see the 250 k rows) named first."""
+  report = _network_case(ME, "Res16UNet34C", None, 1, 3, npos=4096, voxel_size=0.01)
+  msg = "; ".join("%s dev=%.2e ref32=%.2e" % (n_, d_, r_) for d_, r_, n_, g_ in report[:6])
+  print("1 cm worst gradient tensors:", msg)
+  level1 = ("conv0p1s1", "bn0", "convtr7p2s2", "bntr7", "block8", "final")
+  l1 = [(n_, d_, r_) for d_, r_, n_, _ in report if n_.startswith(level1)]
+  print("1 cm level-1 tensors:", "; ".join("%s dev=%.2e ref32=%.2e" % x for x in l1[:8]))
+  assert len(l1) >= 3
+  bad = [(n_, d_, r_) for d_, r_, n_, _ in report if d_ > max(10 * r_, 5e-5)]
+  assert not [x for x in bad if x[0].startswith(level1)], "level-1 gradient tensors off at 1 cm: %s" % (bad[:6],)
+  assert not bad, "gradient tensors off at 1 cm: %s | worst: %s" % (bad[:6], msg)
+
+
 def test_full_config_hardest_trainer_matches_oracle(ME):
   """configs[2]: the full B = 4 Res16UNet34C batch through HardestContrastiveLossTrainer on the native executor.  The
   device's mined negatives must be arg-mins of the ORACLE's features up to 1e-4 (the two feature sets differ by

@@ -770,9 +770,12 @@ class _device_relu_masks:
     return False
 
 
-def _network_case(ME, name, crop, batch, seed, npos=512, voxel_size=0.025):
+def _network_case(ME, name, crop, batch, seed, npos=512, voxel_size=0.025, loss="nce", n_hard=1024):
   """Features / loss / parameter gradients of the device model vs the oracle on one synthetic batch.
-  Returns the per-tensor gradient report [(dev_err, ref32_err, name, |g|max)], worst first."""
+  Returns the per-tensor gradient report [(dev_err, ref32_err, name, |g|max)], worst first.
+  loss = "hardest": the HardestContrastive block (pc/lib/ddp_trainer.py:186-238) with `npos` positives and `n_hard`
+  hard-negative candidates per cloud; the negatives the DEVICE mines are verified as arg-mins of the oracle's features and
+  handed to the oracle (`forced`), which then differentiates the same piecewise-smooth function (test_hardest_loss_parity)."""
   import copy
   from oracle import loss_ref as lr, model_ref as mr, sparse_ref as sr
   from pointcontrast_amd import functional as PF
@@ -795,17 +798,45 @@ def _network_case(ME, name, crop, batch, seed, npos=512, voxel_size=0.025):
   def dev_forward():
     return [dev(ME.SparseTensor(Fin[s], coords=torch.from_numpy(b["sinput%s_C" % s])).to(DEV)).F for s in "01"]
 
+  hard = loss == "hardest"
+  pp = b["correspondences"]
+  if hard:
+    from pointcontrast_amd.lib.ddp_trainer import HardestContrastiveLossTrainer
+    rh = np.random.RandomState(seed + 17)
+    N0, N1 = b["sinput0_C"].shape[0], b["sinput1_C"].shape[0]
+    hd = dict(sel0=rh.choice(N0, min(n_hard, N0), replace=False), sel1=rh.choice(N1, min(n_hard, N1), replace=False),
+              pos_sel=rh.choice(len(pp), min(npos, len(pp)), replace=False))
+    htr = HardestContrastiveLossTrainer.__new__(HardestContrastiveLossTrainer)
+    htr.pos_thresh, htr.neg_thresh = cfg.trainer.pos_thresh, cfg.trainer.neg_thresh
+
   def dev_loss(fd):
+    if hard:
+      pos, neg = htr.contrastive_hardest_negative_loss(fd[0], fd[1], pp, len(hd["pos_sel"]), len(hd["sel0"]), hd)
+      return pos + neg
     q = PF.GatherRowsFunction.apply(fd[0], qi.to(DEV))
     k = PF.GatherRowsFunction.apply(fd[1], ki.to(DEV))
     return PF.NCELossFunction.apply(q, k, 0.4)
+
+  def ref_loss(f, mined=None):
+    if hard:
+      pos, neg, _ = lr.hardest_contrastive_loss(f[0], f[1], pp, hd["sel0"], hd["sel1"], hd["pos_sel"],
+                                                forced=(mined["D01ind"], mined["D10ind"]))
+      return pos + neg
+    return lr.nce_loss(f[0], f[1], qi, ki, 0.4)
+
+  def last_mined():
+    return {k: v.cpu().numpy() for k, v in htr._last_mined.items()} if hard else None
 
   # ---- forward parity, nothing injected: features and loss at 1e-4 on every instance -----------------------------
   fr = [ref(sr.SparseTensorRef(Fin[s], coords=b["sinput%s_C" % s])).F for s in "01"]
   fd = dev_forward()
   for i in range(2):
     assert_rows_close(fd[i], fr[i], 1e-4, "%s features cloud %d" % (name, i))
-  lref, ld = lr.nce_loss(fr[0], fr[1], qi, ki, 0.4), dev_loss(fd)
+  ld = dev_loss(fd)
+  mined = last_mined()
+  if hard:  # (the device mined on ITS features, ~1e-5 from the oracle's: near-ties up to that size are legitimate)
+    _assert_mined_valid(fr[0].detach(), fr[1].detach(), pp, hd, mined, tol=1e-4)
+  lref = ref_loss(fr, mined)
   assert abs(float(ld) - float(lref)) <= 1e-4 * abs(float(lref)), (float(ld), float(lref))
   # BN running statistics were updated twice (two forwards), identically
   assert_close(dev.bn0.bn.running_mean, ref.bn0.bn.running_mean, 1e-4, "bn0 running mean")
@@ -818,15 +849,18 @@ def _network_case(ME, name, crop, batch, seed, npos=512, voxel_size=0.025):
   masks = []
   with mr.relu_masks(record=masks):
     f64 = [ref64(sr.SparseTensorRef(Fin[s].double(), coords=b["sinput%s_C" % s])).F for s in "01"]
-  lr.nce_loss(f64[0], f64[1], qi, ki, 0.4).backward()
-  with mr.relu_masks(apply=masks):
-    f32 = [ref(sr.SparseTensorRef(Fin[s], coords=b["sinput%s_C" % s])).F for s in "01"]
-  lr.nce_loss(f32[0], f32[1], qi, ki, 0.4).backward()
   for p in dev.parameters():
     p.grad = None
   with _device_relu_masks(ME, masks) as inj:
     fdm = dev_forward()
   dev_loss(fdm).backward()
+  mined = last_mined()  # (hardest: of THIS forward -- the three runs differentiate the function these negatives define)
+  if hard:
+    _assert_mined_valid(f64[0].detach().float(), f64[1].detach().float(), pp, hd, mined, tol=1e-4)
+  ref_loss(f64, mined).backward()
+  with mr.relu_masks(apply=masks):
+    f32 = [ref(sr.SparseTensorRef(Fin[s], coords=b["sinput%s_C" % s])).F for s in "01"]
+  ref_loss(f32, mined).backward()
   for i in range(2):
     assert_rows_close(fdm[i], f64[i], 1e-4, "%s features (masks imposed) cloud %d" % (name, i))
   print("%s seed %d: %d of %d ReLU outputs sat on the other side of the kink (%.2e)" %

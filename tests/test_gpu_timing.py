@@ -1,0 +1,87 @@
+"""The executor's measurement mode (include/pcmi.h: pcmi_net_time_all / _timed_ms / _timed_groups_ms / _timed_launches --
+bench.py's families[] and per-layer times): timing every op must not change one bit of a training step, every op of the
+program must come back with a forward and a backward time and a launch count, the convolutions with a weight-gradient time
+or as part of a grouped launch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(seed=3):
+  from pointcontrast_amd.lib import synthetic
+  from pointcontrast_amd.lib.config import get_config
+  from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader, default_collate_pair_fn
+  from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
+  cfg = get_config(["net.model=Res16UNet34C", "misc.nceT=0.4", "misc.npos=512", "opt.lr=0.1", "misc.engine=native"])
+  rng = np.random.RandomState(seed)
+  batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.9) for _ in range(2)])
+  loader = FixedBatchLoader([batch], batch_size=2)
+  torch.manual_seed(seed)
+  return PointNCELossTrainer(cfg, loader), loader, batch
+
+
+def _draws(batch, step):
+  pp = batch["correspondences"].numpy()
+  nq = len(np.unique(pp[:, 0]))
+  return dict(uniform=torch.rand(nq, generator=torch.Generator().manual_seed(step)),
+              sampled_inds=np.random.RandomState(step).choice(nq, min(512, nq), replace=False))
+
+
+def test_timing_every_op_leaves_the_step_bit_identical_and_reports_every_op():
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  runs = []
+  for timed in (False, True):
+    trainer, loader, batch = _trainer()
+    eng = trainer.engine
+    if timed:
+      eng.time_all(3)
+    it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
+    losses = [float(trainer._train_iter(it, timers, draws=_draws(batch, s))["loss"]) for s in range(3)]
+    torch.cuda.synchronize()
+    if timed:
+      recs, groups, counts = eng.timed_ms(3), eng.timed_groups_ms(3), eng.timed_launches(3)
+      eng.time_all(0)
+      assert len(recs) == 3 and len(recs[0][0]) == eng.n_ops
+      for s in range(3):
+        fwd, bwd, wg = recs[s]
+        cf, cb, cw, cg = counts[s]
+        grouped = 0
+        for q, o in enumerate(eng._ops):
+          assert fwd[q] >= 0 and cf[q] >= 1, "op %d: no forward record in set %d" % (q, s)
+          if o["type"] == 0 and o["in_"] == 0:
+            assert bwd[q] < 0, "the input layer has no backward-data launch"
+          else:
+            assert bwd[q] >= 0 and cb[q] >= 1, "op %d: no backward record in set %d" % (q, s)
+          if o["type"] == 0:
+            if wg[q] >= 0:
+              assert cw[q] >= 1
+            else:
+              grouped += 1
+          else:
+            assert wg[q] < 0
+        # convolutions without a record of their own were launched in groups: at least one grouped launch, timed
+        assert (grouped > 0) == (len(groups[s]) > 0), (grouped, groups[s])
+        assert all(g > 0 for g in groups[s]) and sum(cg) >= len(groups[s])
+      tot = sum(t for t in recs[1][0] if t >= 0) + sum(t for t in recs[1][1] if t >= 0)
+      print("Res16UNet34C, 2 pairs: chain ops of set 1 add up to %.2f ms, %d grouped weight-gradient launches" % (tot, len(groups[1])))
+    runs.append((losses, trainer.flat.w.clone()))
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  assert torch.equal(runs[0][1], runs[1][1]), "timing the ops changed the weights"
+
+
+def test_time_ops_accepts_any_op_and_stops():
+  trainer, loader, batch = _trainer()
+  eng = trainer.engine
+  bn = [i for i, o in enumerate(eng._ops) if o["type"] == 1][:3]
+  eng.time_ops(bn, n_sets=2)
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
+  for s in range(2):
+    trainer._train_iter(it, timers, draws=_draws(batch, s))
+  torch.cuda.synchronize()
+  recs = eng.timed_ms(2)
+  eng.time_ops([])
+  for fwd, bwd, wg in recs:
+    assert all(t >= 0 for t in fwd) and all(t >= 0 for t in bwd) and all(t < 0 for t in wg)
