@@ -958,14 +958,17 @@ static Plan make_plan(int64_t rows, int N, int K, bool pair, bool wide = false, 
     // known: x3_workgroups).  The kernel's run time is that of its longest workgroup chain: rounds x (offsets per workgroup
     // x chunks + a fixed share), and "2.5 workgroups per CU" ignores both factors -- on the bench batch it gives the
     // stride-16 level (28 workgroups per split) ksplit 23, i.e. 4 of the 23 z-slices carry TWO offsets and every launch
-    // takes 16 chunk steps where ksplit 27 takes 8; the stride-2 level (316 tiles) ksplit 3 = 948 workgroups on 768
-    // slots, a full round of 27 steps and a quarter-filled second one, where ksplit 2 is ONE round of 42 steps and a
-    // third less partial traffic; the stride-4 128-channel launches 711 workgroups on 512 slots.  cost(ks), in chunk
+    // takes 16 chunk steps where ksplit 27 takes 8; the stride-4 128-channel launches (79 tiles) ksplit 9 = 711 workgroups
+    // on 512 slots, a full round and a 40 %-filled second one, where ksplit 6 is ONE round.  cost(ks), in chunk
     // steps: rounds x (ceil(K / ks) C / 32 + 3) x (a penalty under 2 workgroups per CU: nobody hides a step's latency)
     // + the partial tensors' write + read-back (8 B per element and split at ~3 TB/s against ~2 us per step).  Taken only
-    // when it beats the rule above by 10 % of its own estimate.  PCMI_KSPLIT_RULE=0: the rule above alone (read per call).
+    // when it beats the rule above by 10 % of its own estimate, and only under 16384 rows: on the stride-2 level it picks
+    // ksplit 2, which measured equal in the forward pass and 20 % SLOWER in the backward pass, beside the weight-gradient
+    // stream (profiles/r06d_*: 632 workgroups of 42 steps leave nothing for the other stream to slip into).
+    // PCMI_KSPLIT_RULE=0: the rule above alone (read per call).
     const char* re = getenv("PCMI_KSPLIT_RULE");
-    if (C >= 64 && wide && p.RW == 4 && wgs < target && !(re && re[0] == '0') && conv16_x3(p.NT, C, N) && min16 > 0 && rows >= min16) {
+    if (C >= 64 && wide && p.RW == 4 && wgs < target && rows < 16384 && !(re && re[0] == '0') && conv16_x3(p.NT, C, N) && min16 > 0 &&
+        rows >= min16) {
       const double slots = (double)x3_workgroups(p.NT), nch = (double)(C / kKC);
       const double traffic = (double)rows * N * 8.0 / 3.0e6 / 2.0;  // chunk steps per partial tensor
       auto cost = [&](int ks) {
