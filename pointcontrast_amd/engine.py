@@ -272,7 +272,7 @@ class NativeEngine:
       rc = lib.pcmi_net_backward(self._h, pass_id, ptr(d), d.stride(0), ptr(self.flat.w), ptr(self.flat.g), lo_arr, nb, cb,
                                  None, cur_stream(d.device))
     self._held[pass_id] = None
-    if (errors or rc) and reducer is not None and reducer.active:
+    if (errors or rc) and reducer is not None and (reducer.active or getattr(reducer, "after_bucket", None) is not None):
       # the step is lost either way; leave the reducer in a state the NEXT step can start from
       reducer.abort()
     if errors:  # raised inside a bucket callback: ctypes would have printed and dropped it
@@ -290,7 +290,7 @@ class NativeEngine:
     prints and DROPS a Python exception: the bucket would stay un-reduced on this rank only -- silent divergence between
     the ranks.  The caller re-raises the first entry once pcmi_net_backward has returned."""
     cb, lo_arr, nb = READY_FN(), None, 0
-    if reducer is not None and reducer.active:
+    if reducer is not None and (reducer.active or (getattr(reducer, "after_bucket", None) is not None and reducer.cuda)):
       order = sorted(range(len(reducer.buckets)), key=lambda b: reducer.buckets[b][0])
       lo_arr = (C.c_int64 * len(order))(*[reducer.buckets[b][0] for b in order])
       nb = len(order)

@@ -89,6 +89,14 @@ class ContrastiveLossTrainer:
       self.engine = NativeEngine(model, self.flat, in_channels=num_feats)
     self.optimizer = FlatSGD(self.flat, lr=config.opt.lr, momentum=config.opt.momentum,
                              weight_decay=config.opt.weight_decay, grad_scale=self.reducer.grad_scale)
+    if self.engine is not None and config.misc.get("bucket_sgd", False):
+      # misc.bucket_sgd=True: the optimiser steps a gradient bucket as soon as it is final (and all-reduced), on the
+      # reducer's communication stream beside the rest of the backward pass; optimizer.step() in _backward_and_step covers
+      # what is left (nothing, when every bucket fired).  Same arithmetic bit for bit (tests/test_gpu_timing.py).  OFF by
+      # default: on one GPU it measured 14.33 against 14.14 ms per step (profiles/r06e_*) -- three more launches on a
+      # fourth active stream and three Python callbacks inside the backward enqueue cost more than the 0.13 ms SGD launch
+      # they take off the end of the step; with the 1-rank reducer forced on it is neutral (14.79 / 14.84 ms).
+      self.reducer.after_bucket = lambda b, lo, hi: self.optimizer.step_range(lo, hi)
     self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, config.opt.exp_gamma)
     self.curr_iter = 0
     self.batch_size = data_loader.batch_size if data_loader is not None else config.trainer.batch_size

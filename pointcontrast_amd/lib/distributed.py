@@ -151,6 +151,11 @@ class GradReducer:
     self._launched = [False] * len(self.buckets)
     self._works = []
     self._hooks = []
+    # after_bucket(b, lo, hi): called ON the communication stream as soon as the gradients [lo, hi) of bucket b are final
+    # (all-reduced when the reducer is active, else just complete): the trainer's per-bucket SGD step (lib/solver.py:
+    # FlatSGD.step_range) -- the optimiser then runs beside the rest of the backward pass instead of behind it.  With a
+    # hook set the bucket callbacks fire in a 1-rank world as well (nothing is reduced, the hook is all that happens).
+    self.after_bucket = None
     if self.active:
       for i, p in enumerate(flat.params):
         self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -168,9 +173,18 @@ class GradReducer:
     producer's own way of ordering a stream behind the bucket's gradients (the native executor writes them on two
     streams and joins neither to the other at a bucket boundary: NativeEngine._wait_bucket); without it the
     communication stream waits for the current stream's position, as a DDP bucket hook does."""
-    if not self.active or self._launched[b]:
+    if self._launched[b] or (not self.active and (self.after_bucket is None or not self.cuda)):
       return
     lo, hi, _ = self.buckets[b]
+    if not self.active:  # nothing to reduce: order the stream behind the bucket's producers and run the hook there
+      if order_behind is not None:
+        order_behind(self.comm_stream)
+      else:
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.flat.g.device))
+      self._launched[b] = True
+      with torch.cuda.stream(self.comm_stream):
+        self.after_bucket(b, lo, hi)
+      return
     chunk = self.flat.g[lo:hi]
     if self.cuda and order_behind is not None:
       order_behind(self.comm_stream)  # may raise: the bucket is then NOT marked launched and finish() retries it
@@ -186,17 +200,23 @@ class GradReducer:
       if order_behind is None:
         self.comm_stream.wait_event(ev)
       with torch.cuda.stream(self.comm_stream):
-        self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
+        work = dist.all_reduce(chunk, group=self.pg, async_op=True)
+        self._works.append(work)
+        if self.profile or self.after_bucket is not None:
+          work.wait()  # (stream-level: the communication stream continues behind the collective; the host does not block)
         if self.profile:
           done = torch.cuda.Event(enable_timing=True)
           done.record(self.comm_stream)
           self._prof.append(("bucket", b, (hi - lo) * 4, ev, done))
+        if self.after_bucket is not None:
+          self.after_bucket(b, lo, hi)
     else:
       self._works.append(dist.all_reduce(chunk, group=self.pg, async_op=True))
 
   def finish(self):
-    """Call after backward: launches what is left and makes the compute stream wait for RCCL."""
-    if not self.active:
+    """Call after backward: launches what is left and makes the compute stream wait for RCCL (and for whatever the
+    after_bucket hook enqueued behind it on the communication stream)."""
+    if not self.active and (self.after_bucket is None or not self.cuda):
       return
     for b in range(len(self.buckets)):  # buckets whose parameters received no gradient this step
       self._launch(b)

@@ -21,15 +21,34 @@ class FlatSGD(torch.optim.Optimizer):
     # torch creates a momentum buffer on a parameter's first step as a copy of the gradient (no dampening applied);
     # here the buffers exist (zero-filled) from the start, so "first step" is tracked explicitly
     self._fresh = True
+    self._done = []  # [lo, hi) ranges of the flat buffers this step's step_range calls have already updated
 
   def zero_grad(self, set_to_none=False):
     self.flat.zero_grad()
 
+  def _step_slice(self, lo, hi):
+    g = self.param_groups[0]
+    PF.sgd_step(self.flat.w[lo:hi], self.flat.g[lo:hi], self.flat.v[lo:hi], g["lr"], g["momentum"], g["weight_decay"],
+                self.grad_scale, dampening=g.get("dampening", 0.0), first_step=self._fresh)
+
+  @torch.no_grad()
+  def step_range(self, lo, hi):
+    """The step for the elements [lo, hi) only, on the CURRENT stream: SGD is elementwise, so a step taken in slices is
+    bit for bit the step taken in one launch.  The trainer calls this per gradient bucket as soon as the bucket is final
+    (GradReducer.after_bucket), beside the rest of the backward pass; step() then covers what is left and closes the step."""
+    self._step_slice(int(lo), int(hi))
+    self._done.append((int(lo), int(hi)))
+
   @torch.no_grad()
   def step(self, closure=None):
-    g = self.param_groups[0]
-    PF.sgd_step(self.flat.w, self.flat.g, self.flat.v, g["lr"], g["momentum"], g["weight_decay"], self.grad_scale,
-                dampening=g.get("dampening", 0.0), first_step=self._fresh)
+    pos = 0
+    for lo, hi in sorted(self._done):  # the complement of the ranges already stepped
+      if lo > pos:
+        self._step_slice(pos, lo)
+      pos = max(pos, hi)
+    if pos < self.flat.numel:
+      self._step_slice(pos, self.flat.numel)
+    self._done = []
     self._fresh = False
 
   def state_dict(self):

@@ -9,12 +9,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(seed=3):
+def _trainer(seed=3, extra=()):
   from pointcontrast_amd.lib import synthetic
   from pointcontrast_amd.lib.config import get_config
   from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader, default_collate_pair_fn
   from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
-  cfg = get_config(["net.model=Res16UNet34C", "misc.nceT=0.4", "misc.npos=512", "opt.lr=0.1", "misc.engine=native"])
+  cfg = get_config(["net.model=Res16UNet34C", "misc.nceT=0.4", "misc.npos=512", "opt.lr=0.1", "misc.engine=native"] + list(extra))
   rng = np.random.RandomState(seed)
   batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.9) for _ in range(2)])
   loader = FixedBatchLoader([batch], batch_size=2)
@@ -85,3 +85,30 @@ def test_time_ops_accepts_any_op_and_stops():
   eng.time_ops([])
   for fwd, bwd, wg in recs:
     assert all(t >= 0 for t in fwd) and all(t >= 0 for t in bwd) and all(t < 0 for t in wg)
+
+
+def test_per_bucket_sgd_is_bit_identical_to_the_single_launch():
+  """misc.bucket_sgd=True (off by default: a measured loss on one GPU, profiles/r06e_*): the optimiser steps every gradient bucket on the communication stream as soon as the
+  executor reports it final, beside the rest of the backward pass (GradReducer.after_bucket -> FlatSGD.step_range).
+  SGD is elementwise, so three iterations must leave weights and momentum IDENTICAL to the single launch behind the
+  pass -- and the hook must really have fired for every bucket."""
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  runs = []
+  for on in (True, False):
+    trainer, loader, batch = _trainer(extra=["misc.bucket_sgd=%s" % on])
+    assert (trainer.reducer.after_bucket is not None) == on
+    calls = []
+    if on:
+      assert len(trainer.reducer.buckets) >= 3
+      orig = trainer.optimizer.step_range
+      trainer.optimizer.step_range = lambda lo, hi: (calls.append((lo, hi)), orig(lo, hi))[1]
+    it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
+    losses = [float(trainer._train_iter(it, timers, draws=_draws(batch, s))["loss"]) for s in range(3)]
+    torch.cuda.synchronize()
+    if on:
+      assert len(calls) == 3 * len(trainer.reducer.buckets), calls
+      assert sorted(calls[:len(trainer.reducer.buckets)]) == sorted((lo, hi) for lo, hi, _ in trainer.reducer.buckets)
+    runs.append((losses, trainer.flat.w.clone(), trainer.flat.v.clone()))
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  assert torch.equal(runs[0][1], runs[1][1]), "per-bucket SGD changed the weights"
+  assert torch.equal(runs[0][2], runs[1][2]), "per-bucket SGD changed the momentum"
