@@ -792,8 +792,8 @@ def main():
         else:
           names, extra = ("spconv16p_kernel<3, false, true>",), "sk_fixup_kernel"
         for name in names:
-          if name in per:
-            return per[name] + per.get(extra, 0.0)
+          if name in per:  # (+ the launch's second pass: the fix-up / slab-sum kernel, whatever its template arguments)
+            return per[name] + sum(v for k, v in per.items() if k.startswith(extra))
         return None
 
       def roofline_of(ent):

@@ -143,6 +143,7 @@ struct PassState {
   }
   std::vector<size_t> tensor_off;  // byte offset of every root tensor in `act`
   std::vector<size_t> stat_off;    // per op: BN save_mean/save_invstd (2*C floats) or L2 norms
+  std::vector<size_t> bits_off;    // per op: the ReLU pattern of a BN(+residual)+ReLU output, one bit per element (norm.hip: relu_bits); SIZE_MAX = none
   std::vector<pcmi_kmap_t> maps;   // per op
   std::vector<char> has_map;
   std::vector<int64_t> rows;       // per level
@@ -693,13 +694,14 @@ struct BackwardRun {
       View dr = {nullptr, 0};
       if (op.in2 >= 0) dr = grad_view(n, *ps, op.in2, d_out, d_ld);
       const float* stats0 = (const float*)(ps->act.p + ps->stat_off[i]);
+      const uint32_t* rbits = (op.relu && ps->bits_off[i] != SIZE_MAX) ? (const uint32_t*)(ps->act.p + ps->bits_off[i]) : nullptr;
       const int64_t sp = ps->split[n.tensors[op.in].level];
       if (sp < n_in) {  // a segment = one forward call of the reference: own statistics, own sums; one launch pair
         float* sums = scratch_g + (size_t)(++bn_seen) * scratch_stride;
         int deferred = 0;
         rc = bn_backward2(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, sp, op.cout, params + op.w_off, stats0,
                           stats0 + op.cout, 3 * op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, sums, grads + op.w_off,
-                          grads + op.b_off, ps->ws.p, ps->ws.cap, st, (two_sides || !bn_par) ? nullptr : &deferred);
+                          grads + op.b_off, ps->ws.p, ps->ws.cap, st, (two_sides || !bn_par) ? nullptr : &deferred, rbits);
         if (!rc && deferred) {  // the parameter gradients of this BatchNorm: on the side stream, behind the sums
           PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
           PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_main[0], 0));
@@ -709,7 +711,7 @@ struct BackwardRun {
       } else
         rc = bn_backward(dy.p, dy.ld, x.p, x.ld, op.relu ? y.p : nullptr, y.ld, n_in, op.cout, params + op.w_off, stats0,
                          stats0 + op.cout, dx.p, dx.ld, dr.p, dr.ld, pl.acc_res, scratch_g, scratch_g + op.cout,
-                         grads + op.w_off, grads + op.b_off, ps->ws.p, ps->ws.cap, st);
+                         grads + op.w_off, grads + op.b_off, ps->ws.p, ps->ws.cap, st, rbits);
       if (tb >= 0 && !rc) {
         PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tb + 3], st));
         n.timed_hit[tb] |= 2;
@@ -952,11 +954,21 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     off += align_up((size_t)ps.rows[n.tensors[t].level] * n.tensors[t].channels * sizeof(float), 256);
   }
   ps.stat_off.assign(n_ops, 0);
+  ps.bits_off.assign(n_ops, SIZE_MAX);
+  // PCMI_BN_RELU_BITS=0: the backward BatchNorm kernels read the ReLU pattern from the fp32 output again (A/B; read per pass)
+  const bool relu_bits_on = [] {
+    const char* e = getenv("PCMI_BN_RELU_BITS");
+    return !(e && e[0] == '0');
+  }();
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
     ps.stat_off[i] = off;
     if (op.type == PCMI_OP_BN) off += align_up((size_t)2 * 3 * op.cout * sizeof(float), 256);  // per segment: mean, invstd, unbiased var
     if (op.type == PCMI_OP_L2NORM) off += align_up((size_t)ps.rows[n.tensors[op.in].level] * sizeof(float), 256);
+    if (op.type == PCMI_OP_BN && op.relu && op.cout % 32 == 0 && relu_bits_on && (training & 1)) {
+      ps.bits_off[i] = off;
+      off += align_up((size_t)ps.rows[n.tensors[op.in].level] * (op.cout / 32) * sizeof(uint32_t), 256);
+    }
   }
   rc = ps.act.reserve(off, st);
   if (rc) return rc;
@@ -1096,12 +1108,13 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
       View r = {nullptr, 0};
       if (op.in2 >= 0) r = act_view(n, ps, op.in2);
       float* stats0 = (float*)(ps.act.p + ps.stat_off[i]);
+      uint32_t* rbits = ps.bits_off[i] != SIZE_MAX ? (uint32_t*)(ps.act.p + ps.bits_off[i]) : nullptr;
       if (train) {
         const int64_t sp = ps.split[n.tensors[op.in].level];
         float* stats1 = stats0 + 3 * op.cout;
         if (sp < n_in) {  // both segments in one statistics launch + one apply launch; running estimates via the table
           rc = bn_forward_train2(x.p, x.ld, n_in, sp, op.cout, params + op.w_off, params + op.b_off, op.eps, r.p, r.ld, op.relu,
-                                 y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, 3 * op.cout, ps.ws.p, ps.ws.cap, st);
+                                 y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, 3 * op.cout, ps.ws.p, ps.ws.cap, st, rbits);
           if (op.running_mean)
             ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
                                        stats1, stats1 + 2 * op.cout};
@@ -1109,7 +1122,7 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
           const bool tab = defer || two_seg;
           rc = bn_forward_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off,
                                 tab ? nullptr : op.running_mean, tab ? nullptr : op.running_var, op.momentum, op.eps, r.p,
-                                r.ld, op.relu, y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, ps.ws.p, ps.ws.cap, st);
+                                r.ld, op.relu, y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, ps.ws.p, ps.ws.cap, st, rbits);
           if (tab && op.running_mean)
             ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
                                        nullptr, nullptr};

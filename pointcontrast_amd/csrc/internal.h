@@ -41,12 +41,16 @@ int wgrad_group_flush(WgradGroupBuilder* b, hipStream_t st);
 int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
                 int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
                 int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,
-                float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st);
+                float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st,
+                const uint32_t* relu_bits = nullptr);
+// relu_bits (nullable, norm.hip "relu_bits"): the ReLU pattern of a fused BatchNorm(+residual)+ReLU output as one bit per
+// element, [rows][c / 32] words, c a multiple of 32 -- written by the forward functions when relu != 0, read by the backward
+// ones INSTEAD of relu_mask_y (which may then be null)
 
 int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                      int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean, float* save_invstd,
-                     float* save_unbiased, void* ws, size_t ws_bytes, hipStream_t st);
+                     float* save_unbiased, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* relu_bits = nullptr);
 // deferred running-estimate update of one BatchNorm layer: running = (1 - momentum) * running + momentum * batch
 struct BnRunningUpdate {
   float* running_mean;
@@ -60,11 +64,13 @@ struct BnRunningUpdate {
 };
 int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, int c, const float* gamma, const float* beta,
                       float eps, const float* residual, int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean,
-                      float* save_invstd, float* save_unbiased, int stat_stride, void* ws, size_t ws_bytes, hipStream_t st);
+                      float* save_invstd, float* save_unbiased, int stat_stride, void* ws, size_t ws_bytes, hipStream_t st,
+                      uint32_t* relu_bits = nullptr);
 int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld, int64_t n,
                  int64_t split, int c, const float* gamma, const float* save_mean, const float* save_invstd, int stat_stride,
                  float* dx, int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* sums, float* acc_dgamma,
-                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, int* deferred_acc = nullptr);
+                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, int* deferred_acc = nullptr,
+                 const uint32_t* relu_bits = nullptr);
 // deferred_acc != nullptr: the call MAY leave the parameter-gradient accumulation to the caller (*deferred_acc = 1):
 // bn_param_accumulate(sums, ...) on a stream ordered behind the call, with `sums` untouched until then
 int bn_param_accumulate(const float* sums, int c, float* acc_dgamma, float* acc_dbeta, hipStream_t st);

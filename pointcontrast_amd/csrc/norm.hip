@@ -65,6 +65,21 @@ static RedGeom red_geom(int64_t n, int c) {
   return g;
 }
 
+// ---- the ReLU pattern of a fused BatchNorm(+residual)+ReLU output as ONE BIT per element ("relu_bits") -----------------
+// The backward pass needs of y only whether it is positive.  Reading the fp32 tensor for that is a third of the backward
+// statistics' traffic and a quarter of the apply pass's (67 MB per level-1 BatchNorm of the bench batch, twice); the apply
+// pass of the forward writes the pattern beside y -- bit (c mod 32) of word [row][c / 32], channels a multiple of 32 --
+// and the backward kernels read 4 bytes where they read 128.  Same predicate (y > 0 of the value that was stored), so the
+// gradients are the same bit for bit (tests/test_gpu_parity.py::test_relu_bits_*).  Round 6.
+// nibble of the four channels of float4 column `col` -> a float4 that is positive where the bit is set
+__device__ __forceinline__ float4 relu_bits_as_mask(uint32_t word, int col) {
+  const uint32_t nib = word >> (4 * (col & 7));
+  return make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
+}
+__device__ __forceinline__ uint32_t relu_nibble(const float4& o) {
+  return (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+}
+
 // (n, mean, M2) of a set of rows merged with another set's (Chan et al.), four channels at a time
 __device__ inline void chan_merge(float& n, float4& mean, float4& m2, float on, const float4& omean, const float4& om2) {
   const float tot = n + on;
@@ -181,13 +196,18 @@ __device__ __forceinline__ void colreduce_write(const RedFinal& fin, int t, cons
 
 // MODE 0: (sum x, sum x^2) per block -> (mean_b, M2_b)
 // MODE 1: (sum dy_eff, sum dy_eff * xhat)
-template <int MODE>
+// MASK (MODE 1): 0 no ReLU, 1 the pattern from y (fp32, `ymask`), 2 from `bits` (relu_bits).  A TEMPLATE parameter since
+// round 6: as a run-time `if (ymask)` around the load inside the 4-row batch, hipcc put every row's mask load in a branch
+// of its own with s_waitcnt vmcnt(0) in front of and behind it (hipcc -S) -- eight serialised memory round trips per batch
+// where the batch exists to make it one.  For the same reason a row past the block is no longer `ok ? load : 0` but a load
+// of the block's last row whose contribution is zeroed afterwards (v_cndmask, no branch).
+template <int MODE, int MASK = 0>
 __global__ __launch_bounds__(256) void colreduce_partial_kernel(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld,
     const float* __restrict__ ymask, int64_t y_ld, const float* __restrict__ mean,
     const float* __restrict__ invstd, int64_t n, int c4, int rp, int rows_per_block,
     float* __restrict__ part /* [nblocks][2][c] */, RedFinal fin, int64_t seg_split = 0, int in_seg_stride = 0,
-    int64_t part_seg_stride = 0) {
+    int64_t part_seg_stride = 0, const uint32_t* __restrict__ bits = nullptr /* MODE 1: the ReLU pattern, see relu_bits */) {
   __shared__ float4 s_a[256];
   __shared__ float4 s_b[256];
   __shared__ unsigned s_last;
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
   if (MODE == 1) {
     dy += base * dy_ld;
     if (ymask) ymask += base * y_ld;
+    if (bits) bits += base * (c4 >> 3);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(r0 + (int64_t)rows_per_block, n);
@@ -238,28 +259,34 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
     // rows in batches of kRowBatch: every load of a batch is issued before the first use (a row at a time was one
     // L2 / HBM latency per row and thread -- the small-activation BatchNorms were latency-, not bandwidth-bound)
     constexpr int kRowBatch = 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)rp * kRowBatch) {
       float4 xv[kRowBatch], gv[kRowBatch], yv[kRowBatch];
+      uint32_t wv[kRowBatch];
+      bool ok[kRowBatch];
 #pragma unroll
-      for (int u = 0; u < kRowBatch; ++u) {
+      for (int u = 0; u < kRowBatch; ++u) {  // all loads of the batch, none under a condition
         const int64_t r = rb + (int64_t)u * rp;
-        const bool ok = r < r1;
-        xv[u] = ok ? *reinterpret_cast<const float4*>(x + r * x_ld + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 1) {
-          gv[u] = ok ? *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ymask) yv[u] = ok ? *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        ok[u] = r < r1;
+        const int64_t rc = ok[u] ? r : r1 - 1;  // (r1 > rb >= r0: a valid row)
+        xv[u] = *reinterpret_cast<const float4*>(x + rc * x_ld + col * 4);
+        if constexpr (MODE == 1) {
+          gv[u] = *reinterpret_cast<const float4*>(dy + rc * dy_ld + col * 4);
+          if constexpr (MASK == 1) yv[u] = *reinterpret_cast<const float4*>(ymask + rc * y_ld + col * 4);
+          if constexpr (MASK == 2) wv[u] = bits[rc * (c4 >> 3) + (col >> 3)];
         }
       }
 #pragma unroll
-      for (int u = 0; u < kRowBatch; ++u) {  // (rows past r1 were loaded as zeros: they add nothing)
-        const float4 xq = xv[u];
+      for (int u = 0; u < kRowBatch; ++u) {  // (a row past r1 adds nothing: its x / its gradient is zeroed here)
+        const float4 xq = (MODE == 0 && !ok[u]) ? zero4 : xv[u];
         if (MODE == 0) {
           a.x += xq.x; a.y += xq.y; a.z += xq.z; a.w += xq.w;
           b.x = fmaf(xq.x, xq.x, b.x); b.y = fmaf(xq.y, xq.y, b.y);
           b.z = fmaf(xq.z, xq.z, b.z); b.w = fmaf(xq.w, xq.w, b.w);
         } else {
-          float4 g = gv[u];
-          if (ymask) {
+          float4 g = ok[u] ? gv[u] : zero4;
+          if constexpr (MASK == 2) yv[u] = relu_bits_as_mask(wv[u], col);
+          if constexpr (MASK != 0) {
             g.x = yv[u].x > 0.f ? g.x : 0.f; g.y = yv[u].y > 0.f ? g.y : 0.f;
             g.z = yv[u].z > 0.f ? g.z : 0.f; g.w = yv[u].w > 0.f ? g.w : 0.f;
           }
@@ -314,7 +341,8 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(
 // block's end is an out-of-range offset that reads zeros and adds nothing).  Same partial layout [block][2][c] and the
 // same blocks as the kernel above, so colreduce_final_kernel<1> merges either; the order in which a block's rows are
 // added differs (256 / (c / 2) row lanes), fixed and deterministic all the same.
-template <bool MASKED>
+// MASKED: 0 no ReLU, 1 the pattern from y (fp32), 2 from relu_bits (`ymask` is then the bit tensor, y_ld its words per row)
+template <int MASKED>
 __global__ __launch_bounds__(256, 10) void bn_bwd_stats_lean_kernel(
     const float* __restrict__ x, int64_t x_ld, const float* __restrict__ dy, int64_t dy_ld,
     const float* __restrict__ ymask, int64_t y_ld, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -351,20 +379,32 @@ __global__ __launch_bounds__(256, 10) void bn_bwd_stats_lean_kernel(
 #pragma unroll 1
     for (uint32_t r = first; r < last; r += (uint32_t)(kRows * rp)) {
       lf2 xv[kRows], gv[kRows], yv[kRows];
+      uint32_t wv[kRows];
 #pragma unroll
       for (int u = 0; u < kRows; ++u) {
         const uint32_t ru = r + (uint32_t)(u * rp);
         const bool ok = ru < last;
-        xv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(xr, ok ? ru * xs + cb : kOut, 0, 0));
+        const uint32_t xo = ok ? ru * xs + cb : kOut;
+        xv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(xr, xo, 0, 0));
         gv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(gr, ok ? ru * gs + cb : kOut, 0, 0));
-        if constexpr (MASKED) yv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(yr, ok ? ru * ys + cb : kOut, 0, 0));
+        if constexpr (MASKED == 1) yv[u] = __builtin_bit_cast(lf2, __builtin_amdgcn_raw_buffer_load_b64(yr, ok ? ru * ys + cb : kOut, 0, 0));
+        // MASKED == 2 (the caller guarantees x_ld == c): the row's words are c / 32 and the thread's two channels sit in word
+        // col >> 4 at bits 2 (col & 15), + 1 -- i.e. the word's byte offset is the x element's byte offset / 32, rounded down to
+        // 4: derived from the offset register x already has.  (An offset / shift pair of its own took the kernel from 48 to 49
+        // registers = 56 allocated: it no longer fitted beside a weight-gradient workgroup, the reason this kernel exists.)
+        if constexpr (MASKED == 2) wv[u] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_raw_buffer_load_b32(yr, ok ? ((xo >> 5) & ~3u) : kOut, 0, 0));
       }
 #pragma unroll
       for (int u = 0; u < kRows; ++u) {
         lf2 g = gv[u];
-        if constexpr (MASKED) {
+        if constexpr (MASKED == 1) {
           g[0] = yv[u][0] > 0.f ? g[0] : 0.f;
           g[1] = yv[u][1] > 0.f ? g[1] : 0.f;
+        }
+        if constexpr (MASKED == 2) {  // (a row past the block: g is zero already)
+          const uint32_t nib = wv[u] >> ((cb >> 2) & 30u);  // cb = 8 col
+          g[0] = (nib & 1u) ? g[0] : 0.f;
+          g[1] = (nib & 2u) ? g[1] : 0.f;
         }
         a[0] += g[0];
         a[1] += g[1];
@@ -584,6 +624,7 @@ struct BnSmallFwd {
   const float* gamma; const float* beta;
   int relu;
   RedFinal fin;      // MODE 0 outputs (save_*, running_*, eps, momentum, out_seg_stride)
+  uint16_t* bits;    // nullable: relu_bits as half words -- a workgroup's 16 channels are half of a 32-channel word; [row][c / 16]
 };
 
 // Rows go through raw buffer loads / stores: ONE offset register per operand (row lane x leading dimension + the
@@ -668,6 +709,12 @@ __global__ __launch_bounds__(THREADS) void bn_small_fwd_kernel(BnSmallFwd a) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     small_store(yr, ok ? yo + (uint32_t)(j * RL) * ys : kSmallOut, o);
+    if (a.bits) {  // (uniform) the four lanes of a row lane hold the workgroup's 16 channels of row rl + j RL
+      uint32_t h = relu_nibble(o) << (4 * cg);
+      h |= __shfl_xor(h, 1, 64);
+      h |= __shfl_xor(h, 2, 64);
+      if (cg == 0 && ok) a.bits[(base + rl + j * RL) * (int64_t)gridDim.x + blockIdx.x] = (uint16_t)h;
+    }
   }
 }
 
@@ -682,6 +729,7 @@ struct BnSmallBwd {
   float* dres; int64_t dres_ld; int dres_accumulate;        // nullable
   float* sum_g; float* sum_gx; int sum_stride;              // this call's sums per segment (dbeta, dgamma)
   float* acc_g; float* acc_gx;                               // nullable: parameter gradients, += segment 0, then += segment 1
+  const uint16_t* bits;                                      // nullable: relu_bits (half words, as BnSmallFwd) instead of ymask
 };
 
 // The segments of a two-segment tensor are handled ONE AFTER THE OTHER by the same workgroup: the parameter gradients
@@ -707,7 +755,7 @@ __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
   const uint32_t gs = (uint32_t)a.dy_ld * 4u, xs = (uint32_t)a.x_ld * 4u, ys = (uint32_t)a.y_ld * 4u, ds = (uint32_t)a.dx_ld * 4u,
                  rs = (uint32_t)a.dres_ld * 4u;
   const uint32_t lane_b = (uint32_t)cg * 16u;
-  const bool masked = a.ymask != nullptr, has_res = a.dres != nullptr;
+  const bool masked = a.ymask != nullptr, has_res = a.dres != nullptr, bitmask = a.bits != nullptr;
 #pragma unroll 1
   for (int sg = sg_first; sg < sg_end; ++sg) {
     const int64_t base = sg ? a.split : 0;
@@ -725,7 +773,18 @@ __global__ __launch_bounds__(THREADS) void bn_small_bwd_kernel(BnSmallBwd a) {
       gm[j] = small_load(gr, ok ? (uint32_t)rl * gs + lane_b : kSmallOut, (uint32_t)(j * RL) * gs);
       xh[j] = small_load(xr, ok ? (uint32_t)rl * xs + lane_b : kSmallOut, (uint32_t)(j * RL) * xs);
     }
-    if (masked) {  // (uniform)
+    if (bitmask) {  // (uniform)
+      uint32_t hw[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; ++j)
+        hw[j] = rl + j * RL < ns ? (uint32_t)a.bits[(base + rl + j * RL) * (int64_t)gridDim.x + blockIdx.x] : 0xFFFFu;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const uint32_t nib = hw[j] >> (4 * cg);
+        gm[j].x = (nib & 1u) ? gm[j].x : 0.f; gm[j].y = (nib & 2u) ? gm[j].y : 0.f;
+        gm[j].z = (nib & 4u) ? gm[j].z : 0.f; gm[j].w = (nib & 8u) ? gm[j].w : 0.f;
+      }
+    } else if (masked) {  // (uniform)
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {  // (a row past the segment: gm is zero already, whatever its mask reads)
         const float4 yv = small_load(yr, rl + j * RL < ns ? (uint32_t)rl * ys + lane_b : kSmallOut, (uint32_t)(j * RL) * ys);
@@ -794,6 +853,10 @@ __global__ void bn_param_acc_kernel(float* __restrict__ acc_g, float* __restrict
 }
 
 // y = relu?( (x - mean) * (invstd * gamma) + beta (+ residual) )
+// RES / BITS: residual present / relu_bits written -- template parameters so that every load of an element is issued at the
+// top of its iteration (round 6: the residual load sat in a uniform branch BEHIND the arithmetic with s_waitcnt vmcnt(0)
+// after it, a third memory round trip per element; hipcc -S)
+template <bool RES, bool BITS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t x_ld,
                                                        int64_t n, int c4, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
@@ -801,45 +864,61 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd_or_var, float eps,
                                                        int use_var, const float* __restrict__ res,
                                                        int64_t res_ld, int relu, float* __restrict__ y,
-                                                       int64_t y_ld, int64_t seg_split = INT64_MAX, int seg_stride4 = 0) {
+                                                       int64_t y_ld, int64_t seg_split = INT64_MAX, int seg_stride4 = 0,
+                                                       uint32_t* __restrict__ bits = nullptr /* relu_bits, c4 % 8 == 0 */) {
   const int64_t total = n * c4;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t r = idx / c4;
     const int col = (int)(idx - r * c4);
     const int sc = col + (r >= seg_split ? seg_stride4 : 0);  // rows of the second segment: its own statistics
     const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (RES) rv = *reinterpret_cast<const float4*>(res + r * res_ld + col * 4);
     const float4 mu = reinterpret_cast<const float4*>(mean)[sc];
     float4 is = reinterpret_cast<const float4*>(invstd_or_var)[sc];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[col];
+    const float4 b = reinterpret_cast<const float4*>(beta)[col];
     if (use_var) {
       is.x = 1.0f / sqrtf(is.x + eps); is.y = 1.0f / sqrtf(is.y + eps);
       is.z = 1.0f / sqrtf(is.z + eps); is.w = 1.0f / sqrtf(is.w + eps);
     }
-    const float4 g = reinterpret_cast<const float4*>(gamma)[col];
-    const float4 b = reinterpret_cast<const float4*>(beta)[col];
     float4 o;
     o.x = (xv.x - mu.x) * is.x * g.x + b.x;
     o.y = (xv.y - mu.y) * is.y * g.y + b.y;
     o.z = (xv.z - mu.z) * is.z * g.z + b.z;
     o.w = (xv.w - mu.w) * is.w * g.w + b.w;
-    if (res) {
-      const float4 rv = *reinterpret_cast<const float4*>(res + r * res_ld + col * 4);
+    if constexpr (RES) {
       o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
     }
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
     *reinterpret_cast<float4*>(y + r * y_ld + col * 4) = o;
+    if constexpr (BITS) {  // the 32-channel word of 8 consecutive float4 columns = 8 consecutive lanes: idx = col = lane mod 8,
+      //            and total is a multiple of 8, so the 8 lanes of a word are active together
+      uint32_t w = relu_nibble(o) << (4 * (col & 7));
+      w |= __shfl_xor(w, 1, 64);
+      w |= __shfl_xor(w, 2, 64);
+      w |= __shfl_xor(w, 4, 64);
+      if ((col & 7) == 0) bits[r * (c4 >> 3) + (col >> 3)] = w;
+    }
   }
 }
 
 // dx = gamma * invstd * (g - sum_g/n - xhat * sum_gx/n),  dres = g   (g = relu-masked dy)
+// The mask form and the accumulation stay RUN-TIME conditions here, unlike in the kernels above: with them as template
+// parameters and every load of an element requested up front the kernel needs 50-58 registers (also through raw buffer
+// loads: 52-58), and a workgroup no longer fits beside a wgrad_x3p_kernel workgroup (52 registers per lane are left) -- it
+// then ran on the 32 free compute units only and the level-1 launches got 14 % slower in the step (profiles/r06g_*).  In
+// this form (48 registers) the mask load sits in a branch of its own with a wait behind it; in the step that costs nothing
+// measurable, the co-residency does.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t x_ld,
     const float* __restrict__ ymask, int64_t y_ld, int64_t n, int c4, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ sum_g,
     const float* __restrict__ sum_gx, float* __restrict__ dx, int64_t dx_ld, float* __restrict__ dres,
     int64_t dres_ld, int dres_accumulate, int64_t seg_split = INT64_MAX, int stat_stride4 = 0, int sum_stride4 = 0,
-    float* __restrict__ acc_g = nullptr, float* __restrict__ acc_gx = nullptr) {
+    float* __restrict__ acc_g = nullptr, float* __restrict__ acc_gx = nullptr, const uint32_t* __restrict__ bits = nullptr) {
   const int64_t total = n * c4;
   const bool two = seg_split < n;
   const float inv_n0 = 1.0f / (float)(two ? seg_split : n), inv_n1 = two ? 1.0f / (float)(n - seg_split) : 0.f;
@@ -863,7 +942,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float inv_n = second ? inv_n1 : inv_n0;
     const int sc = col + (second ? stat_stride4 : 0), uc = col + (second ? sum_stride4 : 0);
     float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
-    if (ymask) {
+    if (bits) {
+      const float4 yv = relu_bits_as_mask(bits[r * (c4 >> 3) + (col >> 3)], col);
+      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+    } else if (ymask) {
       const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
@@ -961,6 +1044,10 @@ static int64_t bn_lean_rows() {
   return e ? (int64_t)atoll(e) : (int64_t)65536;
 }
 
+static bool bn_apply_buf_ok(int64_t n, int64_t a, int64_t b, int64_t c_, int64_t d, int64_t e) {  // every tensor of n rows < 2 GiB
+  const int64_t ld = std::max(std::max(std::max(a, b), std::max(c_, d)), e);
+  return n * ld * 4 <= 0x7FFFFF00ll;
+}
 static bool bn_lean_eligible(int64_t n, int c, int64_t x_ld, int64_t dy_ld, int64_t y_ld) {
   const int64_t lean = bn_lean_rows();
   const int64_t ld = std::max(std::max(x_ld, dy_ld), y_ld);
@@ -1001,10 +1088,11 @@ static bool bn_small_eligible(int64_t longest_segment, int c, bool backward = fa
 
 static int bn_small_forward(const float* x, int64_t x_ld, int64_t n, int64_t split, int c, const float* gamma, const float* beta,
                             const float* residual, int64_t res_ld, int relu, float* y, int64_t y_ld, const RedFinal& fin,
-                            hipStream_t st) {
+                            hipStream_t st, uint32_t* relu_bits = nullptr) {
   BnSmallFwd a;
   a.x = x; a.x_ld = x_ld; a.res = residual; a.res_ld = res_ld; a.y = y; a.y_ld = y_ld;
   a.n = n; a.split = split; a.gamma = gamma; a.beta = beta; a.relu = relu; a.fin = fin;
+  a.bits = reinterpret_cast<uint16_t*>(relu_bits);
   const bool two = split < n;
   const int64_t longest = two ? std::max(split, n - split) : n;
   const dim3 grid((unsigned)(c / (4 * kSmallCG)), two ? 2u : 1u);
@@ -1035,6 +1123,24 @@ static int check_rows(const char* who, const void* p, int64_t ld, int c) {
                "%s: needs 16-byte aligned rows, c %% 4 == 0, c <= 1024 (c=%d ld=%lld)", who, c, (long long)ld);
   return PCMI_OK;
 }
+
+// The streaming kernels above take what is uniform per launch (residual / mask form / accumulation) as template parameters:
+// these pick the instantiation.
+#define PCMI_BN_APPLY_LAUNCH(GRID, ST, RES_PTR, BITS_PTR, ...)                                          \
+  do {                                                                                                  \
+    if ((RES_PTR) && (BITS_PTR)) bn_apply_kernel<true, true><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);    \
+    else if (RES_PTR) bn_apply_kernel<true, false><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);              \
+    else if (BITS_PTR) bn_apply_kernel<false, true><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);             \
+    else bn_apply_kernel<false, false><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);                          \
+  } while (0)
+#define PCMI_BN_BWD_APPLY_LAUNCH(GRID, ST, MASK, ACC, BUF, ...) bn_bwd_apply_kernel<<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__)
+#define PCMI_BN_BWD_PARTIAL_LAUNCH(GRID, ST, MASK, ...)                                                 \
+  do {                                                                                                  \
+    const int m_ = (MASK);                                                                              \
+    if (m_ == 2) colreduce_partial_kernel<1, 2><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);                 \
+    else if (m_ == 1) colreduce_partial_kernel<1, 1><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);            \
+    else colreduce_partial_kernel<1, 0><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);                         \
+  } while (0)
 
 static unsigned stream_grid(int64_t total) {
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div(total, 256), 256 * 8));
@@ -1068,7 +1174,8 @@ namespace pcmi {
 int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                      int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean, float* save_invstd,
-                     float* save_unbiased, void* ws, size_t ws_bytes, hipStream_t st) {
+                     float* save_unbiased, void* ws, size_t ws_bytes, hipStream_t st, uint32_t* relu_bits) {
+  if (!relu || c % 32 != 0) relu_bits = nullptr;
   int rc = check_rows("bn_fwd_train(x)", x, x_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_fwd_train(y)", y, y_ld, c);
@@ -1088,7 +1195,7 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
   fin.save_mean = save_mean;
   fin.save_invstd = save_invstd;
   fin.save_unbiased = save_unbiased;
-  if (bn_small_eligible(n, c)) return bn_small_forward(x, x_ld, n, n, c, gamma, beta, residual, res_ld, relu, y, y_ld, fin, st);
+  if (bn_small_eligible(n, c)) return bn_small_forward(x, x_ld, n, n, c, gamma, beta, residual, res_ld, relu, y, y_ld, fin, st, relu_bits);
   if (fuse) {  // statistics + their final merge in ONE launch (last-arriving workgroup), then the apply pass
     fin.counter = stream_counters(st, 1);
     if (!fin.counter) return PCMI_ERR_HIP;
@@ -1106,8 +1213,8 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
                                                                          save_unbiased);
     PCMI_LAUNCH_CHECK();
   }
-  bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
-                                                        res_ld, relu, y, y_ld);
+  PCMI_BN_APPLY_LAUNCH(stream_grid(n * g.c4), st, residual, relu_bits, x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0,
+                       residual, res_ld, relu, y, y_ld, INT64_MAX, 0, relu_bits);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -1117,7 +1224,9 @@ int bn_forward_train(const float* x, int64_t x_ld, int64_t n, int c, const float
 // `stat_stride` floats apart; the running estimates are the caller's business (BnRunningUpdate with mean2).
 int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, int c, const float* gamma, const float* beta,
                       float eps, const float* residual, int64_t res_ld, int relu, float* y, int64_t y_ld, float* save_mean,
-                      float* save_invstd, float* save_unbiased, int stat_stride, void* ws, size_t ws_bytes, hipStream_t st) {
+                      float* save_invstd, float* save_unbiased, int stat_stride, void* ws, size_t ws_bytes, hipStream_t st,
+                      uint32_t* relu_bits) {
+  if (!relu || c % 32 != 0) relu_bits = nullptr;
   int rc = check_rows("bn_fwd_train2(x)", x, x_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_fwd_train2(y)", y, y_ld, c);
@@ -1147,7 +1256,7 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
   fin.out_seg_stride = stat_stride;
   if (bn_small_eligible(longest, c)) {
     fin.counter = nullptr;
-    return bn_small_forward(x, x_ld, n, split, c, gamma, beta, residual, res_ld, relu, y, y_ld, fin, st);
+    return bn_small_forward(x, x_ld, n, split, c, gamma, beta, residual, res_ld, relu, y, y_ld, fin, st, relu_bits);
   }
   const int64_t part_seg = (int64_t)g.nblocks * 2 * c;
 #if defined(PCMI_BN_DIAG_SKIP_SMALL_STATS)  // timing diagnostic (wrong results): as if the producer had left the partials behind
@@ -1162,8 +1271,8 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
                                                                                               part_seg);
     PCMI_LAUNCH_CHECK();
   }
-  bn_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0, residual,
-                                                        res_ld, relu, y, y_ld, split, stat_stride / 4);
+  PCMI_BN_APPLY_LAUNCH(stream_grid(n * g.c4), st, residual, relu_bits, x, x_ld, n, g.c4, gamma, beta, save_mean, save_invstd, eps, 0,
+                       residual, res_ld, relu, y, y_ld, split, stat_stride / 4, relu_bits);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -1173,7 +1282,10 @@ int bn_forward_train2(const float* x, int64_t x_ld, int64_t n, int64_t split, in
 int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld, int64_t n,
                  int64_t split, int c, const float* gamma, const float* save_mean, const float* save_invstd, int stat_stride,
                  float* dx, int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* sums, float* acc_dgamma,
-                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, int* deferred_acc) {
+                 float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, int* deferred_acc, const uint32_t* relu_bits) {
+  if (c % 32 != 0) relu_bits = nullptr;
+  if (relu_bits) relu_mask_y = nullptr;  // the pattern comes from the bits: y is not read
+  const int bits_ld = c / 32;
   int rc = check_rows("bn_bwd2(dy)", dy, dy_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_bwd2(x)", x, x_ld, c);
@@ -1206,10 +1318,12 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
     a.sum_g = sums; a.sum_gx = sums + c; a.sum_stride = 2 * c;
     a.acc_g = deferred_acc ? nullptr : acc_dbeta;
     a.acc_gx = deferred_acc ? nullptr : acc_dgamma;
+    a.bits = reinterpret_cast<const uint16_t*>(relu_bits);
     if (deferred_acc) *deferred_acc = 1;
     return bn_small_backward(a, c, st, deferred_acc != nullptr);
   }
-  const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
+  // (the 48-register kernel finds a row's bit words through x's own offsets: with the bits it needs x_ld == c)
+  const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0) && (!relu_bits || x_ld == c);
   const bool fuse = fuse_final_enabled() && !lean;  // (the lean statistics kernel never merges: it has no registers for it)
   if (fuse) {
     fin.counter = stream_counters(st, 2);
@@ -1222,28 +1336,32 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
 #if defined(PCMI_BN_DIAG_SKIP_SMALL_STATS_BWD)
   if (longest >= PCMI_BN_DIAG_SKIP_SMALL_STATS_BWD)
 #endif
-  if (lean && relu_mask_y)
-    bn_bwd_stats_lean_kernel<true><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
-                                                                                save_invstd, n, c, g.rows_per_block, part, split,
-                                                                                stat_stride, part_seg);
+  if (lean && relu_bits)
+    bn_bwd_stats_lean_kernel<2><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, reinterpret_cast<const float*>(relu_bits),
+                                                                             bits_ld, save_mean, save_invstd, n, c, g.rows_per_block, part,
+                                                                             split, stat_stride, part_seg);
+  else if (lean && relu_mask_y)
+    bn_bwd_stats_lean_kernel<1><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
+                                                                             save_invstd, n, c, g.rows_per_block, part, split,
+                                                                             stat_stride, part_seg);
   else if (lean)
-    bn_bwd_stats_lean_kernel<false><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, nullptr, 0, save_mean, save_invstd,
-                                                                                 n, c, g.rows_per_block, part, split, stat_stride,
-                                                                                 part_seg);
+    bn_bwd_stats_lean_kernel<0><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, nullptr, 0, save_mean, save_invstd,
+                                                                             n, c, g.rows_per_block, part, split, stat_stride,
+                                                                             part_seg);
   else
-    colreduce_partial_kernel<1><<<dim3((unsigned)g.nblocks, 2), 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
-                                                                             save_invstd, n, g.c4, g.rp, g.rows_per_block, part,
-                                                                             fin, split, stat_stride, part_seg);
+    PCMI_BN_BWD_PARTIAL_LAUNCH(dim3((unsigned)g.nblocks, 2), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), x, x_ld, dy, dy_ld, relu_mask_y,
+                               y_ld, save_mean, save_invstd, n, g.c4, g.rp, g.rows_per_block, part, fin, split, stat_stride, part_seg,
+                               relu_bits);
   PCMI_LAUNCH_CHECK();
   if (!fuse) {
     colreduce_final_kernel<1><<<dim3((unsigned)ceil_div(g.c4, kFinalCols), 2), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, split,
                                                                                               part_seg);
     PCMI_LAUNCH_CHECK();
   }
-  bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
-                                                            save_invstd, sums, sums + c, dx, dx_ld, dres, dres_ld,
-                                                            dres_accumulate, split, stat_stride / 4, 2 * c / 4, acc_dbeta,
-                                                            acc_dgamma);
+  PCMI_BN_BWD_APPLY_LAUNCH(stream_grid(n * g.c4), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), dres && dres_accumulate,
+                           bn_apply_buf_ok(n, dy_ld, x_ld, relu_mask_y ? y_ld : 0, dx_ld, dres ? dres_ld : 0), dy, dy_ld, x, x_ld,
+                           relu_mask_y, y_ld, n, g.c4, gamma, save_mean, save_invstd, sums, sums + c, dx, dx_ld, dres, dres_ld,
+                           dres_accumulate, split, stat_stride / 4, 2 * c / 4, acc_dbeta, acc_dgamma, relu_bits);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -1291,8 +1409,8 @@ int pcmi_bn_fwd_eval(const float* x, int64_t x_ld, int64_t n, int c, const float
   if (rc) return rc;
   PCMI_REQUIRE(gamma && beta && running_mean && running_var, PCMI_ERR_INVALID, "bn_fwd_eval: bad argument");
   if (n == 0) return PCMI_OK;
-  bn_apply_kernel<<<stream_grid(n * (c / 4)), 256, 0, as_stream(stream)>>>(x, x_ld, n, c / 4, gamma, beta, running_mean,
-                                                                          running_var, eps, 1, residual, res_ld, relu, y, y_ld);
+  PCMI_BN_APPLY_LAUNCH(stream_grid(n * (c / 4)), as_stream(stream), residual, (uint32_t*)nullptr, x, x_ld, n, c / 4, gamma, beta,
+                       running_mean, running_var, eps, 1, residual, res_ld, relu, y, y_ld, INT64_MAX, 0, (uint32_t*)nullptr);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }
@@ -1304,7 +1422,10 @@ namespace pcmi {
 int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, const float* relu_mask_y, int64_t y_ld,
                 int64_t n, int c, const float* gamma, const float* save_mean, const float* save_invstd, float* dx,
                 int64_t dx_ld, float* dres, int64_t dres_ld, int dres_accumulate, float* dgamma, float* dbeta,
-                float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st) {
+                float* acc_dgamma, float* acc_dbeta, void* ws, size_t ws_bytes, hipStream_t st, const uint32_t* relu_bits) {
+  if (c % 32 != 0) relu_bits = nullptr;
+  if (relu_bits) relu_mask_y = nullptr;
+  const int bits_ld = c / 32;
   int rc = check_rows("bn_bwd(dy)", dy, dy_ld, c);
   if (rc) return rc;
   rc = check_rows("bn_bwd(x)", x, x_ld, c);
@@ -1325,9 +1446,11 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
     a.gamma = gamma; a.mean = save_mean; a.invstd = save_invstd; a.stat_stride = 0;
     a.dx = dx; a.dx_ld = dx_ld; a.dres = dres; a.dres_ld = dres_ld; a.dres_accumulate = dres_accumulate;
     a.sum_g = dbeta; a.sum_gx = dgamma; a.sum_stride = 0; a.acc_g = acc_dbeta; a.acc_gx = acc_dgamma;
+    a.bits = reinterpret_cast<const uint16_t*>(relu_bits);
     return bn_small_backward(a, c, st);
   }
-  const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0);
+  // (the 48-register kernel finds a row's bit words through x's own offsets: with the bits it needs x_ld == c)
+  const bool lean = bn_lean_eligible(n, c, x_ld, dy_ld, relu_mask_y ? y_ld : 0) && (!relu_bits || x_ld == c);
   const bool small = g.nblocks <= kFuseFinalBlocks, fuse = small && fuse_final_enabled() && !lean;
   fin.out_a = dbeta;
   fin.out_b = dgamma;
@@ -1337,15 +1460,18 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
     fin.counter = stream_counters(st, 1);
     if (!fin.counter) return PCMI_ERR_HIP;
   }
-  if (lean && relu_mask_y)
-    bn_bwd_stats_lean_kernel<true><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n, c,
-                                                             g.rows_per_block, part, 0, 0, 0);
+  if (lean && relu_bits)
+    bn_bwd_stats_lean_kernel<2><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, reinterpret_cast<const float*>(relu_bits), bits_ld,
+                                                          save_mean, save_invstd, n, c, g.rows_per_block, part, 0, 0, 0);
+  else if (lean && relu_mask_y)
+    bn_bwd_stats_lean_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n, c,
+                                                          g.rows_per_block, part, 0, 0, 0);
   else if (lean)
-    bn_bwd_stats_lean_kernel<false><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, nullptr, 0, save_mean, save_invstd, n, c,
-                                                              g.rows_per_block, part, 0, 0, 0);
+    bn_bwd_stats_lean_kernel<0><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, nullptr, 0, save_mean, save_invstd, n, c,
+                                                          g.rows_per_block, part, 0, 0, 0);
   else
-    colreduce_partial_kernel<1><<<g.nblocks, 256, 0, st>>>(x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean, save_invstd, n,
-                                                          g.c4, g.rp, g.rows_per_block, part, fin);
+    PCMI_BN_BWD_PARTIAL_LAUNCH(g.nblocks, st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), x, x_ld, dy, dy_ld, relu_mask_y, y_ld, save_mean,
+                               save_invstd, n, g.c4, g.rp, g.rows_per_block, part, fin, (int64_t)0, 0, (int64_t)0, relu_bits);
   PCMI_LAUNCH_CHECK();
   if (small && !fuse) {
     colreduce_final_kernel<1><<<(unsigned)ceil_div(g.c4, kFinalCols), 256, 0, st>>>(part, n, g.c4, g.rows_per_block, fin, 0, 0);
@@ -1355,8 +1481,10 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
     colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
     PCMI_LAUNCH_CHECK();
   }
-  bn_bwd_apply_kernel<<<stream_grid(n * g.c4), 256, 0, st>>>(dy, dy_ld, x, x_ld, relu_mask_y, y_ld, n, g.c4, gamma, save_mean,
-                                                            save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld, dres_accumulate);
+  PCMI_BN_BWD_APPLY_LAUNCH(stream_grid(n * g.c4), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), dres && dres_accumulate,
+                           bn_apply_buf_ok(n, dy_ld, x_ld, relu_mask_y ? y_ld : 0, dx_ld, dres ? dres_ld : 0), dy, dy_ld, x, x_ld,
+                           relu_mask_y, y_ld, n, g.c4, gamma, save_mean, save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld,
+                           dres_accumulate, INT64_MAX, 0, 0, (float*)nullptr, (float*)nullptr, relu_bits);
   PCMI_LAUNCH_CHECK();
   return PCMI_OK;
 }

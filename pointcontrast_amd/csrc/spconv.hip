@@ -709,6 +709,12 @@ __global__ __launch_bounds__(256) void sk_fixup_kernel(const float* __restrict__
 }
 
 // out[row, n] = sum_s partial[s][row, n] (+ bias)
+// (Round 6 measured this kernel, sk_fixup_kernel above and wgrad_slab_sum_kernel with every load of a batch really in flight --
+//  hipcc re-rolls the batch below into one load + s_waitcnt vmcnt(0) per partial tensor -- through clamped indices and template
+//  flags: in the STEP they were not faster (split_reduce 0.76 -> 0.78, sk_fixup 0.45 -> 0.51, slab_sum 0.46 -> 0.55 ms per step of
+//  kernel time, the step itself unchanged: profiles/r06h_*): beside the other streams these passes wait for bandwidth, not
+//  for their own latency.  The forms that did get faster are kept: wgrad_reduce_kernel, colsum_partial_kernel and the
+//  unit-balanced launch's table build in spconv16x_kernel.)
 __global__ void split_reduce_kernel(const float* __restrict__ part, int64_t split_stride, int ksplit,
                                     int64_t n_rows, int N, const float* __restrict__ bias,
                                     float* __restrict__ out, int64_t out_ld, int accumulate) {

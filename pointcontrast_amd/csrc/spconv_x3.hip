@@ -204,11 +204,22 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     if (t < TM) s_orow[t] = (row0 + t < a.n_rows) ? (a.perm ? a.perm[row0 + t] : (int32_t)(row0 + t)) : -1;
     __syncthreads();
     const int cnt = sk_steps > 0 ? o1 - o0 + 1 : 0;
-    for (int p = t; p < cnt * TM; p += 256) {
-      const int q = p / TM, rr = p - q * TM;
+    {  // the piece's table: thread t has row t mod 128 of the offsets t / 128, + 2, + 4, ...  Four table entries are requested at
+       // a time, from clamped (offset, row) indices, and the out-of-range ones dropped afterwards -- round 6: as `row < n ?
+       // nbr[...] : -1` in a one-entry loop this was a load, s_waitcnt vmcnt(0), ds_write per entry (hipcc -S): up to 14
+       // dependent L2 round trips in front of every tile piece of the level-1 launches.
+      const int rr = t & (TM - 1);
       const int64_t row = row0 + rr;
-      const int32_t v = row < a.n_rows ? a.nbr[(int64_t)s_kabs[q] * a.n_rows + row] : -1;
-      s_off[q][rr] = v >= 0 ? (uint32_t)v * ld_bytes : kAbsent;
+      const bool row_ok = row < a.n_rows;
+      const int64_t row_c = row_ok ? row : a.n_rows - 1;
+      for (int q0 = t >> 7; q0 < cnt; q0 += 8) {
+        int32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = a.nbr[(int64_t)s_kabs[min(q0 + 2 * u, cnt - 1)] * a.n_rows + row_c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q0 + 2 * u < cnt) s_off[q0 + 2 * u][rr] = (row_ok && v[u] >= 0) ? (uint32_t)v[u] * ld_bytes : kAbsent;
+      }
     }
   } else {
     int64_t tile = blockIdx.x;

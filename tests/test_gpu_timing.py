@@ -1,7 +1,9 @@
-"""The executor's measurement mode (include/pcmi.h: pcmi_net_time_all / _timed_ms / _timed_groups_ms / _timed_launches --
-bench.py's families[] and per-layer times): timing every op must not change one bit of a training step, every op of the
-program must come back with a forward and a backward time and a launch count, the convolutions with a weight-gradient time
-or as part of a grouped launch."""
+"""Options of the executor / trainer that must not change one bit of a training step:
+  * the measurement mode (include/pcmi.h: pcmi_net_time_all / _timed_ms / _timed_groups_ms / _timed_launches -- bench.py's
+    families[] and per-layer times): every op of the program comes back with a forward and a backward time and a launch
+    count, the convolutions with a weight-gradient time or as part of a grouped launch;
+  * the optimiser per gradient bucket (misc.bucket_sgd);
+  * the ReLU pattern of the fused BatchNorm outputs as one bit per element for the backward pass (csrc/norm.hip: relu_bits)."""
 import numpy as np
 import pytest
 import torch
@@ -9,15 +11,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(seed=3, extra=()):
+def _trainer(seed=3, extra=(), pairs=2, crop=0.9):
   from pointcontrast_amd.lib import synthetic
   from pointcontrast_amd.lib.config import get_config
   from pointcontrast_amd.lib.ddp_data_loaders import FixedBatchLoader, default_collate_pair_fn
   from pointcontrast_amd.lib.ddp_trainer import PointNCELossTrainer
   cfg = get_config(["net.model=Res16UNet34C", "misc.nceT=0.4", "misc.npos=512", "opt.lr=0.1", "misc.engine=native"] + list(extra))
   rng = np.random.RandomState(seed)
-  batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=0.9) for _ in range(2)])
-  loader = FixedBatchLoader([batch], batch_size=2)
+  batch = default_collate_pair_fn([synthetic.make_pair_item(rng, 0.025, crop=crop) for _ in range(pairs)])
+  loader = FixedBatchLoader([batch], batch_size=pairs)
   torch.manual_seed(seed)
   return PointNCELossTrainer(cfg, loader), loader, batch
 
@@ -112,3 +114,25 @@ def test_per_bucket_sgd_is_bit_identical_to_the_single_launch():
   assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
   assert torch.equal(runs[0][1], runs[1][1]), "per-bucket SGD changed the weights"
   assert torch.equal(runs[0][2], runs[1][2]), "per-bucket SGD changed the momentum"
+
+
+@pytest.mark.parametrize("pairs,crop", [(2, 0.9), (4, None)])
+def test_relu_bits_leave_the_step_bit_identical(pairs, crop, monkeypatch):
+  """PCMI_BN_RELU_BITS (default on): the forward BatchNorm apply kernels write (y > 0) as one bit per element beside y and
+  the backward statistics / apply kernels read that instead of the fp32 tensor -- 4 bytes where they read 128.  Same
+  predicate on the same stored values, so two iterations must leave IDENTICAL weights and momentum with the bits and with
+  the fp32 masks.  Second case: the full bench batch (175k rows at level 1: the 48-register statistics kernel, the
+  three-launch kernels, the one-launch kernels of the coarse levels all on their bit-reading paths)."""
+  from pointcontrast_amd.lib.timer import AverageMeter, Timer
+  runs = []
+  for bits in ("1", "0"):
+    monkeypatch.setenv("PCMI_BN_RELU_BITS", bits)  # read per pass by the executor
+    trainer, loader, batch = _trainer(pairs=pairs, crop=crop)
+    it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
+    losses = [float(trainer._train_iter(it, timers, draws=_draws(batch, s))["loss"]) for s in range(2)]
+    torch.cuda.synchronize()
+    runs.append((losses, trainer.flat.w.clone(), trainer.flat.v.clone(), batch["sinput0_C"].shape[0] + batch["sinput1_C"].shape[0]))
+  print("rows per joint pass:", runs[0][3])
+  assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+  assert torch.equal(runs[0][1], runs[1][1]), "the bit pattern changed the weights"
+  assert torch.equal(runs[0][2], runs[1][2]), "the bit pattern changed the momentum"
