@@ -577,8 +577,8 @@ def fp32_instruction_leg(args, steps=10, warmup=5, limit_s=240):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=20)
-  ap.add_argument("--warmup", type=int, default=5)
+  ap.add_argument("--steps", type=int, default=30)
+  ap.add_argument("--warmup", type=int, default=8)  # (arena / pinned-buffer growth and the clocks of a fresh box settle within ~6 iterations)
   ap.add_argument("--batch", type=int, default=4, help="scene pairs per GPU (BASELINE config: 4)")
   ap.add_argument("--voxel", type=float, default=0.025)
   ap.add_argument("--loss", choices=["nce", "hardest"], default="nce")
