@@ -17,6 +17,7 @@ B="python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --no-ex
 stamp "1 bench as the driver runs it"
 timeout 700 python bench.py --layer-table $O/layer_table.tsv > $O/bench_line.json 2> $O/bench.err
 echo "bench exit $?" >> $O/stages.log; cut -c1-300 $O/bench_line.json; echo
+cp $O/layer_table.tsv.times.tsv $O/layer_table_with_in_step_times.tsv 2>/dev/null
 stamp "2 rocprofv3 kernel stats"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o bench -- \
     python "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extra > "$O/prof.log" 2>&1 )
