@@ -538,242 +538,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
   }
 }
 
-// ---- twelve waves, two offsets per workgroup (round 6) ------------------------------------------------------------------
-// Shader-clock stamps around every per-slot barrier of wgrad_x3p_kernel (-DPCMI_X3_DIAG_STAMP, profiles/r06l_*): at level 1,
-// 96 -> 96, a slot lasts 3400 cycles of which the consumers multiply for 2050 (108 MFMAs = 1836) and WAIT for 1360 -- the
-// four producer waves need 3300: 750 to read the offsets and issue 8 gathers, 1860 to convert 24 elements per lane and write
-// 9 cells, 440 for their share of the G rows and the tables.  One producer wave per SIMD is a serial chain of dependent
-// conversions beside a dense MFMA stream; the kernel is bound by it, not by the matrix pipe.  Here a workgroup has EIGHT
-// producer waves (two per SIMD, each other's latency cover) for the same four consumers.  Twelve waves leave 168 registers
-// per lane, so a consumer keeps the accumulators of TWO offsets (72 registers) instead of four: a workgroup owns an offset
-// PAIR, there are 14 offset groups instead of 7 and half as many row blocks -- the G rows of a tile are staged once per
-// two slots instead of four, which the second producer wave per SIMD pays for.
-//   producer task   4 consecutive tile rows (half a row group) x W / 32 channels: 16 x 32 = 512 threads; the 16 lanes of a
-//                   ds_write_b64 service group are the 16 half row groups of one channel (8 cells with distinct XORed slots,
-//                   two 8-byte halves each: 128 consecutive bank bytes) -- conflict-free
-//   slots           q = 2 tile + s; X(q) in s_x[s], G(tile) in s_g[tile & 1]; tables of tile T in ring slot T % 3
-//   step (T, 0)     request X(2T + 3); convert + write X(2T + 1) and G(T + 1); commit the tables of tile T + 2
-//   step (T, 1)     request X(2T + 4) and G(T + 2); convert + write X(2T + 2); request the tables of tile T + 3
-//   (rows are requested three slots / two slots (G) before their conversion; a table's loads one slot before its commit,
-//    and it is first read -- by the requests of step (T, 1) -- one barrier after that)
-// Same cells, fragments, products and per-accumulator order as wgrad_x3p_kernel; the row-block count differs (16 instead of
-// 32 at 27 offsets), so the sums are those of another -- equally fixed -- association.
-template <int MTW, int NTW>
-__global__ __launch_bounds__(768, 1) void wgrad_x3q_kernel(WgradTArgs a) {
-  constexpr int KG = 2, TR = 64, RG = TR / 8;
-  constexpr int CB = 32 * MTW, NB = 32 * NTW;
-  constexpr uint32_t kAbsent = 0x80000000u;
-  constexpr int kRsrcFlags = 0x00020000;
-  __shared__ __attribute__((aligned(16))) u32x4 s_x[2][3 * RG * CB];
-  __shared__ __attribute__((aligned(16))) u32x4 s_g[2][3 * RG * NB];
-  __shared__ __attribute__((aligned(16))) uint32_t s_xoff[3][KG][TR];
-  __shared__ __attribute__((aligned(16))) uint32_t s_goff[3][TR];
-  __shared__ int s_any[3][KG];
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool producer = wave >= 4;
-  const int b = blockIdx.x;
-  const int og = (b >> 3) % a.NG;
-  const int rb = (b & 7) + 8 * (b / (8 * a.NG));
-  const int kbase = og * KG;
-  const int c0 = blockIdx.y * CB, n0 = blockIdx.z * NB;
-  const int n_tiles = (int)((a.n_rows + TR - 1) / TR);
-  const int t0 = rb * a.tiles_per_rb, t1 = min(t0 + a.tiles_per_rb, n_tiles);
-  const int nt_tiles = max(t1 - t0, 0);
-  const int nt2 = (nt_tiles + 1) & ~1;  // the loops run over tile PAIRS (static register-set indices); a tile past the range is absent
-  const uint32_t xld = (uint32_t)(a.x_ld * 4), gld = (uint32_t)(a.g_ld * 4);
-
-  if (producer) {
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7FFFFFFF, kRsrcFlags);
-    const int pt = t - 256, pw = wave - 4;
-    // tables: producer wave 0 / 1 loads the neighbour entries of offset slot 0 / 1, wave 2 the G row of every tile position
-    const int tk = kbase + pw;
-    const int32_t* tsrc = pw < KG ? (a.nbr ? a.nbr + (int64_t)tk * a.n_rows : nullptr) : a.perm;
-    const bool tident = pw < KG ? a.nbr == nullptr : a.perm == nullptr;
-    const bool twave = pw < KG ? tk < a.K : pw == KG;
-    int32_t tab = -1;
-    auto table_issue = [&](int tl) {
-      const int64_t pos = (int64_t)(t0 + tl) * TR + lane;
-      const bool ok = twave && tl < nt_tiles && pos < a.n_rows;
-      // (unconditional reset + ONE guarded load, see wgrad_x3p_kernel)
-      tab = -1;
-      if (ok) tab = tident ? (int32_t)pos : tsrc[pos];
-    };
-    auto table_commit = [&](int tl) {
-      const int sl = tl % 3;
-      if (pw < KG) {
-        s_xoff[sl][pw][lane] = tab >= 0 ? (uint32_t)tab * xld : kAbsent;
-        const bool any = __ballot(tab >= 0) != 0ull;
-        if (lane == 0) s_any[sl][pw] = any ? 1 : 0;
-      } else if (pw == KG) {
-        s_goff[sl][lane] = tab >= 0 ? (uint32_t)tab * gld : kAbsent;
-      }
-    };
-    const int hr = pt & 15, cg = pt >> 4;  // half row group (4 tile rows), channel group
-    struct Row { float f[3]; };            // the (2 or 3) channels of one gathered row
-    auto issue = [&](Row (&v)[4], const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, auto wtag) {
-      constexpr int W = decltype(wtag)::value, CPT = W / 32;
-      const uint32_t col = (uint32_t)(ch0 + CPT * cg) * 4u;
-      const u32x4 o4 = *reinterpret_cast<const u32x4*>(offs + 4 * hr);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {  // an absent row has an offset >= 2^31: out of range, the load returns zeros
-        const uint32_t o = o4[e] + col;
-        if constexpr (CPT == 3) {
-          const auto t3 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, o, 0, 0);
-          __builtin_memcpy(&v[e], &t3, 12);
-        } else {
-          const auto t2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o, 0, 0);
-          __builtin_memcpy(&v[e], &t2, 8);
-        }
-      }
-    };
-    auto finish = [&](u32x4* dst, const Row (&v)[4], auto wtag) {
-      constexpr int W = decltype(wtag)::value, CPT = W / 32;
-      const int rg = hr >> 1, half = hr & 1;
-#pragma unroll
-      for (int ec = 0; ec < CPT; ++ec) {
-        const v4f x = {v[0].f[ec], v[1].f[ec], v[2].f[ec], v[3].f[ec]};
-        u32x2 h, m, l;
-        split3_half(x, h, m, l);
-        const int cell = rg * W + ((CPT * cg + ec) ^ rg);
-        reinterpret_cast<u32x2*>(dst + cell)[half] = h;
-        reinterpret_cast<u32x2*>(dst + RG * W + cell)[half] = m;
-        reinterpret_cast<u32x2*>(dst + 2 * RG * W + cell)[half] = l;
-      }
-    };
-    constexpr std::integral_constant<int, CB> kWX{};
-    constexpr std::integral_constant<int, NB> kWG{};
-    Row r0[4], r1[4], r2[4], r3[4], rgv[4];  // slot q uses set q % 4
-    table_issue(0);
-    table_commit(0);
-    table_issue(1);
-    table_commit(1);
-    table_issue(2);
-    __syncthreads();  // (B0) the first two tables are visible
-    issue(r0, xr, s_xoff[0][0], c0, kWX);
-    issue(rgv, gr, s_goff[0], n0, kWG);
-    issue(r1, xr, s_xoff[0][1], c0, kWX);
-    issue(r2, xr, s_xoff[1][0], c0, kWX);
-    finish(s_x[0], r0, kWX);
-    finish(s_g[0], rgv, kWG);
-    issue(rgv, gr, s_goff[1], n0, kWG);  // G rows of the second tile (converted in step (0, 0))
-    __syncthreads();  // (B1) slot 0 and the G rows of the first tile are staged
-    for (int tl = 0; tl < nt2; tl += 2) {
-      // ---- tile tl: slots 4j, 4j + 1 ----
-      issue(r3, xr, s_xoff[(tl + 1) % 3][1], c0, kWX);
-      finish(s_x[1], r1, kWX);
-      finish(s_g[(tl + 1) & 1], rgv, kWG);
-      table_commit(tl + 2);
-      __syncthreads();
-      issue(r0, xr, s_xoff[(tl + 2) % 3][0], c0, kWX);
-      issue(rgv, gr, s_goff[(tl + 2) % 3], n0, kWG);
-      finish(s_x[0], r2, kWX);
-      table_issue(tl + 3);
-      __syncthreads();
-      // ---- tile tl + 1: slots 4j + 2, 4j + 3 ----
-      issue(r1, xr, s_xoff[(tl + 2) % 3][1], c0, kWX);
-      finish(s_x[1], r3, kWX);
-      finish(s_g[tl & 1], rgv, kWG);
-      table_commit(tl + 3);
-      __syncthreads();
-      issue(r2, xr, s_xoff[(tl + 3) % 3][0], c0, kWX);
-      issue(rgv, gr, s_goff[(tl + 3) % 3], n0, kWG);
-      finish(s_x[0], r0, kWX);
-      table_issue(tl + 4);
-      __syncthreads();
-    }
-    return;
-  }
-
-  // ---- consumers: waves 0-3, 2 x 2 over the [CB x NB] block, MTW x NTW tiles of 16 x 16 each ---------------------------
-  const int i = lane & 15, kk = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x4 acc[KG][MTW][NTW];
-#pragma unroll
-  for (int sx = 0; sx < KG; ++sx)
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[sx][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();  // (B0)
-  __syncthreads();  // (B1)
-  for (int tl = 0; tl < nt2; ++tl) {
-    const u32x4* sg = s_g[tl & 1];
-#pragma unroll
-    for (int sx = 0; sx < KG; ++sx) {
-      if (s_any[tl % 3][sx] != 0) {  // (uniform)
-        const u32x4* sxp = s_x[sx];
-        // (fragment reads pipelined by hand as in wgrad_x3p_kernel: the B fragments of the next column tile are requested
-        //  before the 18 MFMAs of this one; the A fragments of the second 32-row step behind the first step's last tile)
-        u32x4 ah[MTW], am[MTW], al[MTW];
-        u32x4 bh[2], bm[2], bl[2];
-        auto read_a = [&](int step) {
-          const int rgq = 4 * step + kk;
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            const int cell = rgq * CB + ((16 * (wm * MTW + mt) + i) ^ rgq);
-            ah[mt] = sxp[cell];
-            am[mt] = sxp[RG * CB + cell];
-            al[mt] = sxp[2 * RG * CB + cell];
-          }
-        };
-        auto read_b = [&](int step, int nt, int slot) {
-          const int rgq = 4 * step + kk;
-          const int cell = rgq * NB + ((16 * (wn * NTW + nt) + i) ^ rgq);
-          bh[slot] = sg[cell];
-          bm[slot] = sg[RG * NB + cell];
-          bl[slot] = sg[2 * RG * NB + cell];
-        };
-        constexpr int STEPS = TR / 32;
-        read_a(0);
-        read_b(0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int it = 0; it < STEPS * NTW; ++it) {
-          const int step = it / NTW, nt = it % NTW, slot = it & 1;
-          if (it + 1 < STEPS * NTW) read_b((it + 1) / NTW, (it + 1) % NTW, slot ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
-#define PCMI_WX3Q_MFMA(AT, BT)                                                                                                      \
-  acc[sx][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AT[mt]), __builtin_bit_cast(bf16x8, BT[slot]), \
-                                                            acc[sx][mt][nt], 0, 0, 0)
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            PCMI_WX3Q_MFMA(al, bh);
-            PCMI_WX3Q_MFMA(ah, bl);
-            PCMI_WX3Q_MFMA(am, bm);
-            PCMI_WX3Q_MFMA(am, bh);
-            PCMI_WX3Q_MFMA(ah, bm);
-            PCMI_WX3Q_MFMA(ah, bh);
-          }
-#undef PCMI_WX3Q_MFMA
-          __builtin_amdgcn_sched_barrier(0);
-          if (nt == NTW - 1 && step + 1 < STEPS) {
-            read_a(step + 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-#pragma unroll
-  for (int sx = 0; sx < KG; ++sx) {
-    const int k = kbase + sx;
-    if (k >= a.K) continue;
-    float* slab = a.slabs + ((int64_t)k * a.RB + rb) * a.C * a.N;
-#pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = c0 + 16 * (wm * MTW + mt) + 4 * kk + r, n = n0 + 16 * (wn * NTW + nt) + i;
-          slab[(int64_t)c * a.N + n] = acc[sx][mt][nt][r];
-        }
-  }
-}
+// Round 6 measured where a slot of wgrad_x3p_kernel goes (shader-clock stamps, -DPCMI_X3_DIAG_STAMP, profiles/r06l_*): at level 1,
+// 96 -> 96, a slot lasts 3400 cycles of which the consumers multiply for 2050 (108 MFMAs = 1836) and WAIT for 1360; the four
+// producer waves need 3300 -- 750 to read the offsets and issue 8 gathers, 1860 to convert 24 elements per lane (132 VALU
+// operations) and write 9 cells, 440 for their share of the G rows and the tables.  The kernel is bound by the producers' VALU
+// work, at ~7 cycles per instruction beside the consumers' MFMA stream.  What followed from that:
+//   * -fno-slp-vectorize (build.py): hipcc had packed the split's subtractions into v_pk_add_f32 (+ two v_mov per pair), which
+//     costs +13 cycles each beside MFMAs: 0.504 -> 0.438 ms per level-1 launch, the step -2.4 % (profiles/r06n_*);
+//   * a twelve-wave form (EIGHT producer waves, an offset PAIR per workgroup so that the consumers' accumulators fit 168
+//     registers) was built, passed the parity tests and was SLOWER (0.503 against 0.438 ms alone, the step +3 %): the VALU work
+//     per SIMD is the same whichever wave carries it, and the G rows are staged for twice as many offset groups.  Removed;
+//   * with NO producer work at all (split, gather traffic and LDS writes compiled out) the step gains 0.3 ms of 14.0
+//     (profiles/r06j_*): the bound on anything a pre-split operand image could buy, before its own passes are paid for.
 
 // gW[k][e] (+)= sum over the row blocks of slab[k][rb][e], in row-block order.  32 elements x 8 row-block lanes per
 // workgroup, folded through LDS (the chain of dependent loads is RB / 8 long).
@@ -833,11 +609,11 @@ bool wgrad_x3t_eligible(const pcmi_kmap_t* map, int64_t n_in, int64_t n_out, int
          wgrad_x3t_tw(cin) > 0 && wgrad_x3t_tw(cout) > 0 && n_in * in_ld * 4 <= 0x7FFFFF00ll && n_out * gout_ld * 4 <= 0x7FFFFF00ll;
 }
 
-// PCMI_WGRAD_X3P: 2 = twelve waves, an offset pair per workgroup (wgrad_x3q_kernel, round 6), 1 = the round-4
-// producer / consumer form (wgrad_x3p_kernel: 8 waves, four offsets; default), 0 = one role (wgrad_x3t_kernel); read per call
+// PCMI_WGRAD_X3P: 1 = the producer / consumer form (wgrad_x3p_kernel: 8 waves, one workgroup per CU; default), 0 = one role
+// (wgrad_x3t_kernel); read per call
 static int wgrad_x3p_mode() {
   const char* e = getenv("PCMI_WGRAD_X3P");
-  return e ? atoi(e) : 1;
+  return e ? (atoi(e) != 0 ? 1 : 0) : 1;
 }
 
 static int wgrad_x3t_rb(int64_t n_rows, int gy, int gz, int per_cu = 2, int K = PCMI_MAX_KERNEL_VOLUME, int kg = kWgradTKG) {
@@ -861,8 +637,7 @@ size_t wgrad_x3t_workspace(int64_t n_rows, int cin, int cout) {
 
 template <int MTW, int NTW>
 static void launch_x3t(const WgradTArgs& a, dim3 grid, int mode, hipStream_t st) {
-  if (mode >= 2) wgrad_x3q_kernel<MTW, NTW><<<grid, 768, 0, st>>>(a);
-  else if (mode == 1) wgrad_x3p_kernel<MTW, NTW, kWgradTKG><<<grid, 512, 0, st>>>(a);
+  if (mode == 1) wgrad_x3p_kernel<MTW, NTW, kWgradTKG><<<grid, 512, 0, st>>>(a);
   else wgrad_x3t_kernel<MTW, NTW, kWgradTKG><<<grid, 256, 0, st>>>(a);
 }
 
@@ -885,7 +660,7 @@ int wgrad_x3t_run(const float* in, int64_t in_ld, const float* gout, int64_t gou
   const int gy = cin / (32 * MTW), gz = cout / (32 * NTW);
   const int mode = wgrad_x3p_mode();
   [[maybe_unused]] const bool pc = mode == 1;
-  const int kg = mode >= 2 ? 2 : kWgradTKG;
+  const int kg = kWgradTKG;
   a.NG = (K + kg - 1) / kg;
   a.RB = wgrad_x3t_rb(n_rows, gy, gz, mode >= 1 ? 1 : 2, K, kg);
   // (the producer / consumer form takes 8 x NG x (RB / 8) = 224 of the 256 CUs at NG = 7: with every CU used -- 36 row

@@ -41,20 +41,4 @@ __device__ __forceinline__ void split3(const v4f& x0, const v4f& x1, u32x4& h, u
   }
 }
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-// the same for 4 floats -> three vectors of 4 bf16 (two dwords each); element for element the values of split3
-__device__ __forceinline__ void split3_half(const v4f& x, u32x2& h, u32x2& m, u32x2& l) {
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const float xa = x[2 * p], xb = x[2 * p + 1];
-    const unsigned hp = cvt_pk_bf16(xa, xb);
-    const float ra = xa - bf16_lo(hp), rb = xb - bf16_hi(hp);  // exact
-    const unsigned mp = cvt_pk_bf16(ra, rb);
-    const float sa = ra - bf16_lo(mp), sb = rb - bf16_hi(mp);  // exact
-    h[p] = hp;
-    m[p] = mp;
-    l[p] = cvt_pk_bf16(sa, sb);
-  }
-}
-
 }  // namespace pcmi

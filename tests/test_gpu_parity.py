@@ -1371,13 +1371,13 @@ def test_conv16_x3_split_precision_matches_fp32(ME, size, cin, cout, dma, monkey
       json.dump(report, f)
 
 
-@pytest.mark.parametrize("form", ["twelve_waves", "producer_consumer", "one_role"])
+@pytest.mark.parametrize("form", ["producer_consumer", "one_role"])
 @pytest.mark.parametrize("size,cin,cout", [("mid", 64, 64), ("mid", 96, 96), ("large", 96, 96), ("large", 128, 96),
                                            ("large", 64, 128), ("large", 192, 128)])
 def test_wgrad_x3t_split_precision_matches_fp64(ME, size, cin, cout, form, monkeypatch):
-  """The three forms of the tile-stationary kernel -- wgrad_x3q_kernel (round 6: twelve waves, eight of them staging, an
-  offset pair per workgroup, PCMI_WGRAD_X3P=2, the default), wgrad_x3p_kernel (round 4: eight waves, four offsets per
-  workgroup, =1) and wgrad_x3t_kernel (round 3, =0): the same cells, fragments and products.
+  """Both forms of the tile-stationary kernel -- wgrad_x3p_kernel (round 4: staging and multiplying waves, one 8-wave
+  workgroup per CU, PCMI_WGRAD_X3P=1, the default) and wgrad_x3t_kernel (round 3, =0): the same cells, fragments and
+  products.
   wgrad_x3t_kernel (csrc/spconv_wgrad_x3.hip: output-tile stationary, both operands as three bf16 terms through
   contraction-packed LDS cells, six v_mfma_f32_16x16x32_bf16 per tile) against the pair-list fp32-MFMA kernel
   (PCMI_WGRAD_X3T=0) and against a float64 contraction, on operands with a wide dynamic range.  The split form must be
@@ -1399,7 +1399,7 @@ def test_wgrad_x3t_split_precision_matches_fp64(ME, size, cin, cout, form, monke
   for k in range(27):
     ok = nbr[k] >= 0
     g64[k] = x[nbr[k][ok]].double().t() @ g[ok].double()
-  monkeypatch.setenv("PCMI_WGRAD_X3P", {"twelve_waves": "2", "producer_consumer": "1", "one_role": "0"}[form])
+  monkeypatch.setenv("PCMI_WGRAD_X3P", "1" if form == "producer_consumer" else "0")
   res = {}
   for mode in ("0", "1"):
     monkeypatch.setenv("PCMI_WGRAD_X3T", mode)  # 0: the pair-list kernel; 1: the tile-stationary kernel at every size
