@@ -272,6 +272,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
   const uint32_t xld = (uint32_t)(a.x_ld * 4), gld = (uint32_t)(a.g_ld * 4);
 
   if (producer) {
+#if defined(PCMI_X3P_PRIO_P)  // A/B: wave priority of the staging waves
+    __builtin_amdgcn_s_setprio(PCMI_X3P_PRIO_P);
+#endif
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7FFFFFFF, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g), 0, 0x7FFFFFFF, kRsrcFlags);
     const int pt = t - 256;
@@ -313,15 +316,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
     // idle and the operand split -- what bounds this kernel -- on three SIMDs instead of four).  8 consecutive lanes take the
     // 8 row groups of the same channels: the LDS write pattern the XOR in the cell address is made for.
     const int rg_s = pt & 7, q_s = pt >> 3;
-    auto issue = [&](auto& v, const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, auto wtag) {
-      constexpr int W = decltype(wtag)::value, CPT = W / 32;
+    auto issue = [&](auto& v, const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* offs, int ch0, auto wtag, auto e0tag, auto e1tag) {
+      constexpr int W = decltype(wtag)::value, CPT = W / 32, E0 = decltype(e0tag)::value, E1 = decltype(e1tag)::value;
 #if defined(PCMI_X3_DIAG_NO_GATHER)  // timing diagnostic (wrong results): every row out of range = no memory traffic
       const uint32_t col = kAbsent;
 #else
       const uint32_t col = (uint32_t)(ch0 + CPT * q_s) * 4u;
 #endif
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {  // an absent row has an offset >= 2^31: out of range, the load returns zeros
+      for (int e = E0; e < E1; ++e) {  // an absent row has an offset >= 2^31: out of range, the load returns zeros
 #if defined(PCMI_X3_DIAG_NO_GATHER)
         const uint32_t o = (offs[8 * rg_s + e] & 0xFFFFu) | col;
 #else
@@ -338,10 +341,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
         }
       }
     };
-    auto finish = [&](u32x4* dst, const auto& v, auto wtag) {
-      constexpr int W = decltype(wtag)::value, CPT = W / 32;
+    auto finish = [&](u32x4* dst, const auto& v, auto wtag, auto c0tag, auto c1tag) {
+      constexpr int W = decltype(wtag)::value, CPT = W / 32, EC0 = decltype(c0tag)::value, EC1 = decltype(c1tag)::value;
 #pragma unroll
-      for (int ec = 0; ec < CPT; ++ec) {
+      for (int ec = EC0; ec < (EC1 < CPT ? EC1 : CPT); ++ec) {
         const v4f x0 = {v[0].f[ec], v[1].f[ec], v[2].f[ec], v[3].f[ec]}, x1 = {v[4].f[ec], v[5].f[ec], v[6].f[ec], v[7].f[ec]};
         u32x4 h, m, l;
 #if defined(PCMI_X3_DIAG_NO_SPLIT)  // timing diagnostic (wrong results)
@@ -362,6 +365,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
     struct Row { float f[3]; };  // the (2 or 3) channels of one gathered row
     constexpr std::integral_constant<int, CB> kWX{};
     constexpr std::integral_constant<int, NB> kWG{};
+    constexpr std::integral_constant<int, 0> k0{};
+    constexpr std::integral_constant<int, 8> k8{};
     // FOUR register sets for the gathered rows (the producers own no accumulators): the rows of slot q + 3 are requested in
     // step q and converted in step q + 2 -- two full steps in flight (with two sets / one step the step lasted as long as
     // a gather under load: 0.54 ms per level-0 launch, profiles/r04j_*); slot s of a tile uses set s (KG = 4).  The G rows
@@ -386,13 +391,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
     table_issue(1);
     table_commit(1);
     __syncthreads();  // (B0) the first two tables are visible
-    issue(r0, xr, s_xoff[0][0], c0, kWX);
-    issue(rgv, gr, s_goff[0], n0, kWG);
-    issue(r1, xr, s_xoff[0][1], c0, kWX);
-    issue(r2, xr, s_xoff[0][2], c0, kWX);
-    finish(s_x[0], r0, kWX);
-    finish(s_g[0], rgv, kWG);
-    issue(rgv, gr, s_goff[1], n0, kWG);  // G rows of the second tile (converted in step 1)
+    issue(r0, xr, s_xoff[0][0], c0, kWX, k0, k8);
+    issue(rgv, gr, s_goff[0], n0, kWG, k0, k8);
+    issue(r1, xr, s_xoff[0][1], c0, kWX, k0, k8);
+    issue(r2, xr, s_xoff[0][2], c0, kWX, k0, k8);
+    finish(s_x[0], r0, kWX, k0, k8);
+    finish(s_g[0], rgv, kWG, k0, k8);
+    issue(rgv, gr, s_goff[1], n0, kWG, k0, k8);  // G rows of the second tile (converted in step 1)
     __syncthreads();  // (B1) slot 0 and the G rows of the first tile are staged
 #define PCMI_X3P_SET(j) ((j) == 0 ? r0 : ((j) == 1 ? r1 : ((j) == 2 ? r2 : r3)))
 #if defined(PCMI_X3_DIAG_STAMP)
@@ -405,15 +410,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
         if (sx == 0) table_issue(tl + 2);
         {  // rows of slot q + 3 into the register set slot q - 1 has left (converted two steps ago)
           const int s3 = (sx + 3) % KG, tl3 = tl + (sx + 3) / KG;
-          issue(PCMI_X3P_SET(s3), xr, s_xoff[tl3 % 3][s3], c0, kWX);
+          issue(PCMI_X3P_SET(s3), xr, s_xoff[tl3 % 3][s3], c0, kWX, k0, k8);
         }
         PCMI_X3P_PHASE(1);
-        // slot q + 1 (requested two steps ago): convert and write into the X buffer the consumers are not reading
-        finish(s_x[(sx + 1) & 1], PCMI_X3P_SET((sx + 1) % KG), kWX);
+        // slot q + 1 (requested two steps ago): convert and write into the X buffer the consumers are not reading.
+        // (Round 6 measured the order of the two: the 8 requests of a wave take ~780 of a step's 2830 cycles -- four waves'
+        //  gathers queue on the CU's one address unit -- and neither the conversion first nor a channel's conversion behind
+        //  every few requests hides that: 0.491 / 0.436 against 0.435 ms per level-1 launch, profiles/r06pq_*.)
+        finish(s_x[(sx + 1) & 1], PCMI_X3P_SET((sx + 1) % KG), kWX, k0, k8);
         PCMI_X3P_PHASE(2);
-        if (sx == 1) finish(s_g[(tl + 1) & 1], rgv, kWG);
+        if (sx == 1) finish(s_g[(tl + 1) & 1], rgv, kWG, k0, k8);
         if (sx == KG - 2) table_commit(tl + 2);  // (first read one step on: a barrier away)
-        if (sx == KG - 1) issue(rgv, gr, s_goff[(tl + 2) % 3], n0, kWG);  // (its table: written one step ago)
+        if (sx == KG - 1) issue(rgv, gr, s_goff[(tl + 2) % 3], n0, kWG, k0, k8);  // (its table: written one step ago)
         PCMI_X3P_PHASE(3);
         PCMI_X3P_BARRIER(tl * KG + sx, 1);
       }
@@ -427,6 +435,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3p_kernel(WgradTArgs a) {
   }
 
   // ---- consumers: waves 0-3, 2 x 2 over the [CB x NB] block, MTW x NTW tiles of 16 x 16 each ---------------------------
+#if defined(PCMI_X3P_PRIO_C)  // A/B: wave priority of the multiplying waves
+  __builtin_amdgcn_s_setprio(PCMI_X3P_PRIO_C);
+#endif
   const int i = lane & 15, kk = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   f32x4 acc[KG][MTW][NTW];
