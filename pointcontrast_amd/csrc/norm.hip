@@ -906,12 +906,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // dx = gamma * invstd * (g - sum_g/n - xhat * sum_gx/n),  dres = g   (g = relu-masked dy)
-// The mask form and the accumulation stay RUN-TIME conditions here, unlike in the kernels above: with them as template
-// parameters and every load of an element requested up front the kernel needs 50-58 registers (also through raw buffer
-// loads: 52-58), and a workgroup no longer fits beside a wgrad_x3p_kernel workgroup (52 registers per lane are left) -- it
-// then ran on the 32 free compute units only and the level-1 launches got 14 % slower in the step (profiles/r06g_*).  In
-// this form (48 registers) the mask load sits in a branch of its own with a wait behind it; in the step that costs nothing
-// measurable, the co-residency does.
+// MASK / DRES are template parameters and every load of an element is requested at the top of its iteration -- except the old
+// residual gradient of DRES == 2, which a compiler barrier keeps below the arithmetic: four more live registers at the top cost
+// the co-residency.  The register count is what decides this kernel in the step: a workgroup must fit beside a wgrad_x3p_kernel
+// workgroup (52 registers per lane are left), or it runs on the 32 free compute units only and the level-1 launches get 14 %
+// slower (profiles/r06g_*: the same form needed 50-58 registers then and lost).  Since the library is built with
+// -fno-slp-vectorize the forms the step uses need 46-48 (the fp32-mask forms of PCMI_BN_RELU_BITS=0: 49-50): BatchNorm backward
+// 2.54 -> 2.46 ms in the step, the step itself unchanged (profiles/r06s_*).
+template <int MASK, int DRES>  // MASK 0: none, 1: fp32 y, 2: relu_bits; DRES 0: none, 1: store, 2: accumulate
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, int64_t dy_ld, const float* __restrict__ x, int64_t x_ld,
     const float* __restrict__ ymask, int64_t y_ld, int64_t n, int c4, const float* __restrict__ gamma,
@@ -941,17 +943,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const bool second = r >= seg_split;
     const float inv_n = second ? inv_n1 : inv_n0;
     const int sc = col + (second ? stat_stride4 : 0), uc = col + (second ? sum_stride4 : 0);
+    // every load of the element is requested here, before any of them is used
     float4 g = *reinterpret_cast<const float4*>(dy + r * dy_ld + col * 4);
-    if (bits) {
-      const float4 yv = relu_bits_as_mask(bits[r * (c4 >> 3) + (col >> 3)], col);
-      g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
-      g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
-    } else if (ymask) {
-      const float4 yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
+    uint32_t bw = 0;
+    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if constexpr (MASK == 2) bw = bits[r * (c4 >> 3) + (col >> 3)];
+    if constexpr (MASK == 1) yv = *reinterpret_cast<const float4*>(ymask + r * y_ld + col * 4);
+    if constexpr (MASK == 2) yv = relu_bits_as_mask(bw, col);
+    if constexpr (MASK != 0) {
       g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
       g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
     }
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * x_ld + col * 4);
     const float4 mu = reinterpret_cast<const float4*>(mean)[sc];
     const float4 is = reinterpret_cast<const float4*>(invstd)[sc];
     const float4 ga = reinterpret_cast<const float4*>(gamma)[col];
@@ -963,13 +966,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     o.z = ga.z * is.z * (g.z - sg.z * inv_n - (xv.z - mu.z) * is.z * sx.z * inv_n);
     o.w = ga.w * is.w * (g.w - sg.w * inv_n - (xv.w - mu.w) * is.w * sx.w * inv_n);
     *reinterpret_cast<float4*>(dx + r * dx_ld + col * 4) = o;
-    if (dres) {
-      float4* dp = reinterpret_cast<float4*>(dres + r * dres_ld + col * 4);
-      if (dres_accumulate) {
-        const float4 o = *dp;
-        g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+    if constexpr (DRES != 0) {
+      if constexpr (DRES == 2) {  // (requested here, not at the top: four more live registers there cost the co-residency)
+        asm volatile("" ::: "memory");  // (keeps the request below the arithmetic: the compiler would hoist it)
+        const float4 dold = *reinterpret_cast<const float4*>(dres + r * dres_ld + col * 4);
+        g.x += dold.x; g.y += dold.y; g.z += dold.z; g.w += dold.w;
       }
-      *dp = g;
+      *reinterpret_cast<float4*>(dres + r * dres_ld + col * 4) = g;
     }
   }
 }
@@ -1133,7 +1136,20 @@ static int check_rows(const char* who, const void* p, int64_t ld, int c) {
     else if (BITS_PTR) bn_apply_kernel<false, true><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);             \
     else bn_apply_kernel<false, false><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__);                          \
   } while (0)
-#define PCMI_BN_BWD_APPLY_LAUNCH(GRID, ST, MASK, ACC, BUF, ...) bn_bwd_apply_kernel<<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__)
+#define PCMI_BN_BWD_APPLY_CASE(M, D, GRID, ST, ...) \
+  case (M) * 3 + (D): bn_bwd_apply_kernel<M, D><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__); break
+#define PCMI_BN_BWD_APPLY_LAUNCH(GRID, ST, MASK, DRESMODE, BUF, ...)                     \
+  switch ((MASK) * 3 + (DRESMODE)) {                                                      \
+    PCMI_BN_BWD_APPLY_CASE(0, 0, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(0, 1, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(0, 2, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(1, 0, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(1, 1, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(1, 2, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(2, 0, GRID, ST, __VA_ARGS__);                                  \
+    PCMI_BN_BWD_APPLY_CASE(2, 1, GRID, ST, __VA_ARGS__);                                  \
+    default: bn_bwd_apply_kernel<2, 2><<<(GRID), 256, 0, (ST)>>>(__VA_ARGS__); break;     \
+  }
 #define PCMI_BN_BWD_PARTIAL_LAUNCH(GRID, ST, MASK, ...)                                                 \
   do {                                                                                                  \
     const int m_ = (MASK);                                                                              \
@@ -1358,7 +1374,7 @@ int bn_backward2(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, c
                                                                                               part_seg);
     PCMI_LAUNCH_CHECK();
   }
-  PCMI_BN_BWD_APPLY_LAUNCH(stream_grid(n * g.c4), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), dres && dres_accumulate,
+  PCMI_BN_BWD_APPLY_LAUNCH(stream_grid(n * g.c4), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), dres ? (dres_accumulate ? 2 : 1) : 0,
                            bn_apply_buf_ok(n, dy_ld, x_ld, relu_mask_y ? y_ld : 0, dx_ld, dres ? dres_ld : 0), dy, dy_ld, x, x_ld,
                            relu_mask_y, y_ld, n, g.c4, gamma, save_mean, save_invstd, sums, sums + c, dx, dx_ld, dres, dres_ld,
                            dres_accumulate, split, stat_stride / 4, 2 * c / 4, acc_dbeta, acc_dgamma, relu_bits);
@@ -1481,7 +1497,7 @@ int bn_backward(const float* dy, int64_t dy_ld, const float* x, int64_t x_ld, co
     colsum2_final_kernel<<<dim3((unsigned)ceil_div(c, 4)), 256, 0, st>>>(part, g.nblocks, c, dbeta, dgamma, acc_dbeta, acc_dgamma);
     PCMI_LAUNCH_CHECK();
   }
-  PCMI_BN_BWD_APPLY_LAUNCH(stream_grid(n * g.c4), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), dres && dres_accumulate,
+  PCMI_BN_BWD_APPLY_LAUNCH(stream_grid(n * g.c4), st, relu_bits ? 2 : (relu_mask_y ? 1 : 0), dres ? (dres_accumulate ? 2 : 1) : 0,
                            bn_apply_buf_ok(n, dy_ld, x_ld, relu_mask_y ? y_ld : 0, dx_ld, dres ? dres_ld : 0), dy, dy_ld, x, x_ld,
                            relu_mask_y, y_ld, n, g.c4, gamma, save_mean, save_invstd, dbeta, dgamma, dx, dx_ld, dres, dres_ld,
                            dres_accumulate, INT64_MAX, 0, 0, (float*)nullptr, (float*)nullptr, relu_bits);
