@@ -28,6 +28,7 @@
 // (161 TFLOP/s of fp32-equivalent work: above the 157.3 TFLOP/s peak of the fp32 instruction), 128->128 at level 2
 // 0.341 -> 0.170 ms; max |difference| to the fp32 kernel 0.9-2.9e-6 of the largest output.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -122,6 +123,19 @@ __global__ __launch_bounds__(256) void x3_pack_many_kernel(const X3PackJob* __re
 // stand-alone timing only (pointcontrast_amd.build.build_variant + PCMI_LIB; profiles/r04e_kernel_component_removal.txt
 // is what they showed: no single component bounds the kernel, and it is NOT memory latency -- requesting the gathers, or
 // gathers and weight blocks, two steps ahead changed nothing: profiles/r04b_*, r04f_*).
+#if defined(PCMI_X3_DIAG_STAMP)  // timing diagnostic: shader-clock totals of one wave's phases (workgroup 17, wave 0)
+__device__ unsigned long long g_x3c_phase[8];
+#define PCMI_X3C_PHASE(P)                                          \
+  do {                                                             \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long t_ph = __builtin_readcyclecounter();  \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    ph_sum[P] += t_ph - ph_last;                                   \
+    ph_last = t_ph;                                                \
+  } while (0)
+#else
+#define PCMI_X3C_PHASE(P) do {} while (0)
+#endif
 template <int NT, bool SK, bool DMA>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArgs a) {
   constexpr int TM = 128, NS = 32 * NT, CTN = 2 * NT;  // rows per tile, output slice, 16-wide column tiles
@@ -176,6 +190,9 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
   const uint32_t ld_bytes = (uint32_t)(a.x_ld * 4);
   const int sk_total = SK ? sk_u1 - sk_u : 0;
   int sk_done = 0, prio_qtr = -1;
+#if defined(PCMI_X3_DIAG_STAMP)
+  unsigned long long ph_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+#endif
   for (;;) {  // one pass per tile piece (exactly one when !SK)
   bool sk_whole = true;
   int sk_next_u = 0, sk_c0 = 0, sk_steps = 0;
@@ -347,6 +364,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     store_b(0);
     __syncthreads();  // (DMA: the barrier's fence waits for the block to have landed)
     auto do_step = [&](int step, v4f (&cur)[2][2], int va_cur, v4f (&nxt)[2][2], int& va_nxt) {
+      PCMI_X3C_PHASE(0);  // everything between two steps (tile prologue / epilogue, table build)
       const bool more = step + 1 < nsteps;
       if constexpr (SK) {  // issue priority falls with the workgroup's progress through its share (spconv16p_kernel)
         const int qtr = __builtin_amdgcn_readfirstlane(((sk_done + step) * 4) / max(sk_total, 1));
@@ -368,6 +386,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
       if (g0) split3(cur[0][0], cur[0][1], ah[0], am[0], al[0]);
       if (g1) split3(cur[1][0], cur[1][1], ah[1], am[1], al[1]);
 #endif
+      PCMI_X3C_PHASE(1);  // priority + operand split
       // B fragments of column tile ct: piece (term, n = 16 ct + i, kk); a two-tile register ring, read one tile ahead
       const u32x4* sb = &s_b[step & 1][kk * 16 + i];  // x3_piece(16 ct + i, kk) = 64 ct + this
       u32x4 bh[2], bm[2], bl[2];
@@ -425,12 +444,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
         if (ct == 2) va_nxt = stage_a(nxt, more);
         __builtin_amdgcn_sched_barrier(0);
       }
+      PCMI_X3C_PHASE(2);  // fragment reads, MFMAs, next step's requests
+#if defined(PCMI_X3_DIAG_STAMP)
+      if (va_cur) ph_sum[4] += 1; else ph_sum[5] += 1;
+#endif
       if (more) store_b((step + 1) & 1);
 #if defined(PCMI_X3_DIAG_NO_BARRIER)  // timing diagnostic (racy): the waves of a workgroup never meet
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #else
       __syncthreads();
 #endif
+      PCMI_X3C_PHASE(3);  // barrier
     };
     for (int step = 0; step < nsteps; step += 2) {
       do_step(step, a0, va0, a1, va1);
@@ -482,6 +506,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 3) void spconv16x_kernel(ConvArg
     __syncthreads();  // s_off / s_orow / the staging area are rewritten by the next piece
   }
   }  // for (;;)
+#if defined(PCMI_X3_DIAG_STAMP)
+  if (blockIdx.x == 17 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    for (int e = 0; e < 8; ++e) g_x3c_phase[e] = ph_sum[e];
+#endif
 }
 
 template <bool SK, bool DMA>
@@ -493,6 +521,17 @@ static int launch_x3(int NT, const ConvArgs& a, dim3 grid, hipStream_t st) {
     default: set_error("spconv x3: bad NT %d", NT); return PCMI_ERR_INVALID;
   }
   PCMI_LAUNCH_CHECK();
+#if defined(PCMI_X3_DIAG_STAMP)
+  {
+    unsigned long long h[8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_x3c_phase), sizeof(h));
+    const double ns = (double)(h[4] + h[5]);
+    if (ns > 0)
+      fprintf(stderr, "x3c phases: NT %d sk %d C %d rows %lld grid %u,%u,%u | steps %.0f (%.0f absent) | per step: split %.0f | reads + MFMAs + requests %.0f | barrier %.0f | between steps %.0f\n",
+              NT, SK ? 1 : 0, a.C, (long long)a.n_rows, grid.x, grid.y, grid.z, ns, (double)h[5], h[1] / ns, h[2] / ns, h[3] / ns, h[0] / ns);
+  }
+#endif
   return PCMI_OK;
 }
 
