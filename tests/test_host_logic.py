@@ -491,3 +491,14 @@ def test_hardest_draws_consume_the_global_generator_in_the_reference_order():
   np.random.seed(7)
   T._draw_hardest(N0, N1, P, num_pos, num_hn, inj)
   assert np.random.rand() == first, "injected draws must not touch the global generator"
+
+
+def test_build_flags_are_part_of_the_measurement_stamp(monkeypatch):
+  """profiles/pmc_traffic.json is stamped with sources_digest(); a PMC pass belongs to a BUILD, so the digest must move with
+  the compiler flags too (round 6: -fno-slp-vectorize changed every matrix-bound kernel's duration without touching a
+  source line), and the product flags must carry that switch."""
+  from pointcontrast_amd import build as b
+  assert "-fno-slp-vectorize" in b.FLAGS and "--offload-arch=gfx950" in b.FLAGS
+  d0 = b.sources_digest()
+  monkeypatch.setattr(b, "FLAGS", [f for f in b.FLAGS if f != "-fno-slp-vectorize"])
+  assert b.sources_digest() != d0
