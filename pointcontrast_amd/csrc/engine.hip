@@ -200,6 +200,7 @@ struct pcmi_net {
   // what produced the gradient bucket the running `ready` callback is about: the chain up to the bucket's last op on
   // the backward stream, and the weight gradients enqueued so far on the side stream (pcmi_net_stream_wait_bucket)
   hipEvent_t ev_bkt_main = nullptr, ev_bkt_side[kSides] = {nullptr, nullptr};
+  hipEvent_t ev_fwd_fork = nullptr, ev_fwd_join = nullptr;  // forward pass: a block's residual branch on the side stream
   bool bkt_valid = false, bkt_side[kSides] = {false, false};
   pcmi::DevBuf ws_side[kSides];
   // weight gradients of the coarse levels collected for ONE launch per run of layers (spconv_wgrad.hip: wgrad_group_*)
@@ -253,6 +254,8 @@ struct pcmi_net {
       if (ev_bkt_side[i]) (void)hipEventDestroy(ev_bkt_side[i]);
     }
     if (ev_bkt_main) (void)hipEventDestroy(ev_bkt_main);
+    if (ev_fwd_fork) (void)hipEventDestroy(ev_fwd_fork);
+    if (ev_fwd_join) (void)hipEventDestroy(ev_fwd_join);
   }
 };
 
@@ -1092,53 +1095,111 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     for (size_t q = 0; q < per; ++q) n.timed_hit[base + q] = 0;
     if (n.timed_keep_groups) n.timed_group_n[n.timed_cur % n.timed_sets] = 0;
   }
-  for (int i = 0; i < n_ops; ++i) {
+  // ---- the residual branch of a block beside its main path (round 6) ------------------------------------------------------
+  // A BasicBlock whose channel count changes computes its residual with a 1x1 convolution + BatchNorm of the block's INPUT
+  // (pc/model/resnet.py: downsample); the traced program lists the two behind conv1 / bn1 / conv2 although they depend on
+  // nothing the main path computes.  They go to the side stream -- idle during a forward pass but for the weight packs -- as
+  // soon as the block's input is complete, with the side workspace, and the BatchNorm that adds the residual waits for them.
+  // Same kernels on the same operands: bit-identical results (tests/test_gpu_timing.py).  PCMI_FWD_BRANCH=0: in program order.
+  std::vector<int> fork_at(n_ops, -1), join_before(n_ops, -1);
+  std::vector<char> on_side(n_ops, 0);
+  {
+    const char* e = getenv("PCMI_FWD_BRANCH");
+    if (!(e && e[0] == '0') && late_first_op < 0) {
+      for (int i = 3; i + 2 < n_ops; ++i) {
+        const auto &c = n.ops[i], &b1 = n.ops[i + 1], &b2 = n.ops[i + 2];
+        if (c.type != PCMI_OP_CONV || c.kernel_size != 1 || b1.type != PCMI_OP_BN || b1.in != c.out || b1.relu || b1.in2 >= 0 ||
+            b2.type != PCMI_OP_BN || b2.in2 != b1.out)
+          continue;
+        int s0 = -1;
+        for (int q = i - 3; q < i; ++q)
+          if (n.ops[q].in == c.in && !on_side[q]) {
+            s0 = q;
+            break;
+          }
+        if (s0 < 0 || fork_at[s0] >= 0) continue;
+        fork_at[s0] = i;
+        on_side[i] = on_side[i + 1] = 1;
+        join_before[i + 2] = i;
+      }
+    }
+  }
+  bool any_fork = false;
+  for (int i = 0; i < n_ops; ++i) any_fork |= fork_at[i] >= 0;
+  if (any_fork) {
+    rc = ensure_streams(n, false);
+    if (rc) return rc;
+    rc = n.ws_side[0].reserve(ps.ws.cap, n.side[0]);
+    if (rc) return rc;
+    if (!n.ev_fwd_fork) PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fwd_fork, hipEventDisableTiming));
+    if (!n.ev_fwd_join) PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fwd_join, hipEventDisableTiming));
+  }
+  auto run_op = [&](int i, hipStream_t sq, DevBuf& w) -> int {
     const auto& op = n.ops[i];
     const View x = act_view(n, ps, op.in), y = act_view(n, ps, op.out);
     const int64_t n_in = ps.rows[n.tensors[op.in].level], n_out = ps.rows[n.tensors[op.out].level];
-    if (i == late_first_op) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));  // (PCMI_DEBUG_LATE_WGRAD)
-    const int tq = n.timed_slot(i);
-    if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 0], st));
-    const long lf0 = g_launches;
-    if (op.type == PCMI_OP_CONV) {
-      rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
-                          op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, ps.ws.p, ps.ws.cap,
-                          st);
-    } else if (op.type == PCMI_OP_BN) {
-      View r = {nullptr, 0};
-      if (op.in2 >= 0) r = act_view(n, ps, op.in2);
-      float* stats0 = (float*)(ps.act.p + ps.stat_off[i]);
-      uint32_t* rbits = ps.bits_off[i] != SIZE_MAX ? (uint32_t*)(ps.act.p + ps.bits_off[i]) : nullptr;
-      if (train) {
-        const int64_t sp = ps.split[n.tensors[op.in].level];
-        float* stats1 = stats0 + 3 * op.cout;
-        if (sp < n_in) {  // both segments in one statistics launch + one apply launch; running estimates via the table
-          rc = bn_forward_train2(x.p, x.ld, n_in, sp, op.cout, params + op.w_off, params + op.b_off, op.eps, r.p, r.ld, op.relu,
-                                 y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, 3 * op.cout, ps.ws.p, ps.ws.cap, st, rbits);
-          if (op.running_mean)
-            ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
-                                       stats1, stats1 + 2 * op.cout};
+    int rc = PCMI_OK;
+      const int tq = n.timed_slot(i);
+      if (tq >= 0) PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 0], sq));
+      const long lf0 = g_launches;
+      if (op.type == PCMI_OP_CONV) {
+        rc = spconv_forward(x.p, x.ld, n_in, op.cin, params + op.w_off, op.cout, ps.has_map[i] ? &ps.maps[i] : nullptr,
+                            op.transpose, op.has_bias ? params + op.b_off : nullptr, y.p, y.ld, n_out, 0, w.p, w.cap,
+                            sq);
+      } else if (op.type == PCMI_OP_BN) {
+        View r = {nullptr, 0};
+        if (op.in2 >= 0) r = act_view(n, ps, op.in2);
+        float* stats0 = (float*)(ps.act.p + ps.stat_off[i]);
+        uint32_t* rbits = ps.bits_off[i] != SIZE_MAX ? (uint32_t*)(ps.act.p + ps.bits_off[i]) : nullptr;
+        if (train) {
+          const int64_t sp = ps.split[n.tensors[op.in].level];
+          float* stats1 = stats0 + 3 * op.cout;
+          if (sp < n_in) {  // both segments in one statistics launch + one apply launch; running estimates via the table
+            rc = bn_forward_train2(x.p, x.ld, n_in, sp, op.cout, params + op.w_off, params + op.b_off, op.eps, r.p, r.ld, op.relu,
+                                   y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, 3 * op.cout, w.p, w.cap, sq, rbits);
+            if (op.running_mean)
+              ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
+                                         stats1, stats1 + 2 * op.cout};
+          } else {
+            const bool tab = defer || two_seg;
+            rc = bn_forward_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off,
+                                  tab ? nullptr : op.running_mean, tab ? nullptr : op.running_var, op.momentum, op.eps, r.p,
+                                  r.ld, op.relu, y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, w.p, w.cap, sq, rbits);
+            if (tab && op.running_mean)
+              ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
+                                         nullptr, nullptr};
+          }
         } else {
-          const bool tab = defer || two_seg;
-          rc = bn_forward_train(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off,
-                                tab ? nullptr : op.running_mean, tab ? nullptr : op.running_var, op.momentum, op.eps, r.p,
-                                r.ld, op.relu, y.p, y.ld, stats0, stats0 + op.cout, stats0 + 2 * op.cout, ps.ws.p, ps.ws.cap, st, rbits);
-          if (tab && op.running_mean)
-            ps.upd_host[ps.upd_n++] = {op.running_mean, op.running_var, stats0, stats0 + 2 * op.cout, op.cout, op.momentum,
-                                       nullptr, nullptr};
+          rc = pcmi_bn_fwd_eval(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
+                                op.running_var, op.eps, r.p, r.ld, op.relu, y.p, y.ld, (void*)sq);
         }
       } else {
-        rc = pcmi_bn_fwd_eval(x.p, x.ld, n_in, op.cout, params + op.w_off, params + op.b_off, op.running_mean,
-                              op.running_var, op.eps, r.p, r.ld, op.relu, y.p, y.ld, stream);
+        rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), (void*)sq);
       }
-    } else {
-      rc = pcmi_l2norm_fwd(x.p, x.ld, n_in, op.cout, y.p, y.ld, (float*)(ps.act.p + ps.stat_off[i]), stream);
+      if (rc) return rc;
+      if (tq >= 0) {
+        PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 1], sq));
+        n.timed_hit[tq] |= 1;
+        n.timed_cnt[3 * tq + 0] = (int)(g_launches - lf0);
+      }
+    return PCMI_OK;
+  };
+  for (int i = 0; i < n_ops; ++i) {
+    const auto& op = n.ops[i];
+    if (i == late_first_op) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));  // (PCMI_DEBUG_LATE_WGRAD)
+    if (fork_at[i] >= 0) {  // everything enqueued so far is the branch's input (and more): the branch starts behind it
+      PCMI_HIP_CHECK(hipEventRecord(n.ev_fwd_fork, st));
+      PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_fwd_fork, 0));
+      rc = run_op(fork_at[i], n.side[0], n.ws_side[0]);
+      if (rc) return rc;
+      rc = run_op(fork_at[i] + 1, n.side[0], n.ws_side[0]);
+      if (rc) return rc;
+      PCMI_HIP_CHECK(hipEventRecord(n.ev_fwd_join, n.side[0]));
     }
-    if (rc) return rc;
-    if (tq >= 0) {
-      PCMI_HIP_CHECK(hipEventRecord(n.timed_ev[pcmi_net::kTimedEv * tq + 1], st));
-      n.timed_hit[tq] |= 1;
-      n.timed_cnt[3 * tq + 0] = (int)(g_launches - lf0);
+    if (join_before[i] >= 0) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_fwd_join, 0));
+    if (!on_side[i]) {
+      rc = run_op(i, st, ps.ws);
+      if (rc) return rc;
     }
     if (i == pack_bwd_at) {  // the side stream starts behind this point of the pass (and behind the job table's upload)
       PCMI_HIP_CHECK(hipEventRecord(n.ev_main[0], st));
