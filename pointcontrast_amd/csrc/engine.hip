@@ -164,6 +164,7 @@ struct PassState {
   const float* x3_params = nullptr;
   bool x3_current = false;  // the last forward of this pass packed (the packs are those of its weights)
   int x3_n_jobs = 0;
+  int x3_first_op = -1;
   int64_t x3_items = 0;
   // The jobs are ordered forward orientations first: [0, x3_items_fwd) is packed at the top of the forward pass, on its
   // stream; the backward-data orientations [x3_items_fwd, x3_items) -- not needed before the backward pass -- are packed
@@ -200,7 +201,7 @@ struct pcmi_net {
   // what produced the gradient bucket the running `ready` callback is about: the chain up to the bucket's last op on
   // the backward stream, and the weight gradients enqueued so far on the side stream (pcmi_net_stream_wait_bucket)
   hipEvent_t ev_bkt_main = nullptr, ev_bkt_side[kSides] = {nullptr, nullptr};
-  hipEvent_t ev_fwd_fork = nullptr, ev_fwd_join = nullptr;  // forward pass: a block's residual branch on the side stream
+  hipEvent_t ev_fwd_fork = nullptr, ev_fwd_join = nullptr, ev_fwd_pack = nullptr;  // forward pass: a block's residual branch on the side stream
   bool bkt_valid = false, bkt_side[kSides] = {false, false};
   pcmi::DevBuf ws_side[kSides];
   // weight gradients of the coarse levels collected for ONE launch per run of layers (spconv_wgrad.hip: wgrad_group_*)
@@ -256,6 +257,7 @@ struct pcmi_net {
     if (ev_bkt_main) (void)hipEventDestroy(ev_bkt_main);
     if (ev_fwd_fork) (void)hipEventDestroy(ev_fwd_fork);
     if (ev_fwd_join) (void)hipEventDestroy(ev_fwd_join);
+    if (ev_fwd_pack) (void)hipEventDestroy(ev_fwd_pack);
   }
 };
 
@@ -320,12 +322,15 @@ static int x3_prepack(pcmi_net& n, PassState& ps, const float* params, hipStream
   }
   const std::vector<int64_t>& rows = ps.rows;
   std::vector<int> nts;
-  for (const auto& op : n.ops) {
+  ps.x3_first_op = -1;  // the first op whose forward launch reads a pack (the forward pass joins a side-stream pack there)
+  for (size_t oi = 0; oi < n.ops.size(); ++oi) {
+    const auto& op = n.ops[oi];
     if (op.type != PCMI_OP_CONV || op.kernel_size <= 1) continue;
     const int K = op.kernel_size * op.kernel_size * op.kernel_size;
     for (int tr = 0; tr < 2; ++tr) {
       const int C = tr ? op.cout : op.cin, N = tr ? op.cin : op.cout;
       nts.push_back(x3_plan_nt(rows[n.tensors[tr ? op.in : op.out].level], C, N, K));
+      if (tr == 0 && nts.back() >= 2 && ps.x3_first_op < 0) ps.x3_first_op = (int)oi;
     }
   }
   if (ps.x3_params != params || nts != ps.x3_nts) {
@@ -1017,7 +1022,28 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
     const char* e = getenv("PCMI_X3_PACK_SPLIT");
     return !(e && e[0] == '0');
   }();
-  rc = x3_prepack(n, ps, params, st, pack_split);
+  // PCMI_X3_PACK_SIDE (round 6, default on for training passes): the forward orientations are packed on the side stream, behind
+  // everything enqueued so far, and the pass waits for them in front of the first convolution that reads a pack -- the stem and
+  // the 32-channel layers of the first two levels (~0.45 ms) do not.  (Round 5 measured this at +0.3 %, inside the spread, with a
+  // join in front of the first convolution of ANY kind; the residual branches above use the same stream.)
+  const bool pack_side = train0 && [] {
+    const char* e = getenv("PCMI_X3_PACK_SIDE");
+    return !(e && e[0] == '0');
+  }();
+  bool pack_joined = true;
+  if (pack_side) {
+    rc = ensure_streams(n, false);
+    if (rc) return rc;
+    if (!n.ev_fwd_fork) PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fwd_fork, hipEventDisableTiming));
+    if (!n.ev_fwd_pack) PCMI_HIP_CHECK(hipEventCreateWithFlags(&n.ev_fwd_pack, hipEventDisableTiming));
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_fwd_fork, st));
+    PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_fwd_fork, 0));
+    rc = x3_prepack(n, ps, params, n.side[0], pack_split);
+    PCMI_HIP_CHECK(hipEventRecord(n.ev_fwd_pack, n.side[0]));
+    pack_joined = false;
+  } else {
+    rc = x3_prepack(n, ps, params, st, pack_split);
+  }
   const X3TableScope x3_scope;  // the table is this thread's only until the pass has been enqueued
   if (rc) return rc;
   // where the backward-data orientations are packed: behind the first op of the third level (the pass is in its
@@ -1187,6 +1213,10 @@ int pcmi_net_forward(pcmi_net_t* net, int pass, pcmi_coords_t* coords, const flo
   for (int i = 0; i < n_ops; ++i) {
     const auto& op = n.ops[i];
     if (i == late_first_op) PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_side[0], 0));  // (PCMI_DEBUG_LATE_WGRAD)
+    if (!pack_joined && (i >= ps.x3_first_op || fork_at[i] >= 0)) {  // (a forked 1x1 layer may pack for itself on the side stream: keep it simple)
+      PCMI_HIP_CHECK(hipStreamWaitEvent(st, n.ev_fwd_pack, 0));
+      pack_joined = true;
+    }
     if (fork_at[i] >= 0) {  // everything enqueued so far is the branch's input (and more): the branch starts behind it
       PCMI_HIP_CHECK(hipEventRecord(n.ev_fwd_fork, st));
       PCMI_HIP_CHECK(hipStreamWaitEvent(n.side[0], n.ev_fwd_fork, 0));

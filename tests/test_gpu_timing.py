@@ -138,23 +138,26 @@ def test_relu_bits_leave_the_step_bit_identical(pairs, crop, monkeypatch):
   assert torch.equal(runs[0][2], runs[1][2]), "the bit pattern changed the momentum"
 
 
+@pytest.mark.parametrize("switch", ["PCMI_FWD_BRANCH", "PCMI_X3_PACK_SIDE"])
 @pytest.mark.parametrize("pairs,crop", [(2, 0.9), (4, None)])
-def test_residual_branches_on_the_side_stream_leave_the_step_bit_identical(pairs, crop, monkeypatch):
+def test_residual_branches_on_the_side_stream_leave_the_step_bit_identical(pairs, crop, switch, monkeypatch):
   """PCMI_FWD_BRANCH (default on): the 1x1 convolution + BatchNorm that compute a BasicBlock's residual (pc/model/resnet.py:
   downsample) run on the executor's side stream beside conv1 / bn1 / conv2 of the block and the BatchNorm that adds the
-  residual waits for them.  Same kernels on the same operands in the same per-tensor order: two iterations must leave
-  IDENTICAL losses, weights, momentum and BatchNorm running estimates with the branches forked and in program order."""
+  residual waits for them.  PCMI_X3_PACK_SIDE (default on): the forward orientations of the split-precision weights are
+  packed on that stream too and the pass waits for them in front of the first convolution that reads a pack.  Same kernels on
+  the same operands in the same per-tensor order: two iterations must leave IDENTICAL losses, weights, momentum and BatchNorm
+  running estimates with the switch on and off."""
   from pointcontrast_amd.lib.timer import AverageMeter, Timer
   runs = []
   for mode in ("1", "0"):
-    monkeypatch.setenv("PCMI_FWD_BRANCH", mode)  # read per pass by the executor
+    monkeypatch.setenv(switch, mode)  # read per pass by the executor
     trainer, loader, batch = _trainer(pairs=pairs, crop=crop)
     it, timers = iter(loader), [AverageMeter(), Timer(), Timer()]
-    losses = [float(trainer._train_iter(it, timers, draws=_draws(batch, s))["loss"]) for s in range(2)]
+    losses = [float(trainer._train_iter(it, timers, draws=_draws(batch, s))["loss"]) for s in range(3)]
     torch.cuda.synchronize()
     bufs = torch.cat([b.detach().flatten().float() for b in trainer.model.buffers()])
     runs.append((losses, trainer.flat.w.clone(), trainer.flat.v.clone(), bufs.clone()))
   assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
-  assert torch.equal(runs[0][1], runs[1][1]), "the forked branches changed the weights"
-  assert torch.equal(runs[0][2], runs[1][2]), "the forked branches changed the momentum"
-  assert torch.equal(runs[0][3], runs[1][3]), "the forked branches changed the BatchNorm running estimates"
+  assert torch.equal(runs[0][1], runs[1][1]), "%s changed the weights" % switch
+  assert torch.equal(runs[0][2], runs[1][2]), "%s changed the momentum" % switch
+  assert torch.equal(runs[0][3], runs[1][3]), "%s changed the BatchNorm running estimates" % switch
